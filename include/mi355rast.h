@@ -1,0 +1,177 @@
+/*
+ * mi355rast.h -- C ABI of libmi355rast.so, the MI355X (gfx950) rasteriser behind
+ * py_numpy_renderer_amd.Scene.render().
+ *
+ * The reference (Denizantip/py-numpy-renderer) has no FFI: its boundary for this path is
+ * the Python call Scene.render() -> uint8 (H, W, 3) (obj/core.py:587-640).  Each entry
+ * point below names the reference code it stands in for; a host in any language binds
+ * these symbols (INTEGRATION.md shows the ctypes stub).
+ *
+ * Conventions: plain pointers and sizes only; every function returns MR_OK (0) or a
+ * negative MR_E_* code and never throws; mr_last_error() describes the last failure on the
+ * calling thread.  The caller owns every host pointer it passes (they may be freed as soon
+ * as the call returns); the library owns all device memory.  A scene is used from one
+ * thread at a time.  Matrices are row-major float64 in the reference's row-vector
+ * convention (clip = v @ MVP).
+ */
+#ifndef MI355RAST_H
+#define MI355RAST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_ABI_VERSION 1
+
+enum {
+    MR_OK = 0,
+    MR_E_INVALID = -1,      /* bad argument / inconsistent sizes */
+    MR_E_DEVICE = -2,       /* HIP runtime error (no GPU, out of memory, launch failure) */
+    MR_E_UNSUPPORTED = -3,  /* feature of the reference that this build does not implement */
+    MR_E_OVERFLOW = -4      /* internal work list could not be grown */
+};
+
+/* light kinds: obj/lightning.py:4-7 */
+enum { MR_LIGHT_DIRECTIONAL = 0, MR_LIGHT_POINT = 1, MR_LIGHT_SPOT = 2 };
+
+/* per-face result of the lit pass, numerically the reference's Errors flag (obj/triangular.py:15-20) */
+enum {
+    MR_FACE_RENDERED = 0, MR_FACE_BACK_FACE_CULLING = 1, MR_FACE_WRONG_MIN_MAX = 2,
+    MR_FACE_EMPTY_B = 4, MR_FACE_EMPTY_Z = 8, MR_FACE_CLIPPED = 16
+};
+
+/* mr_frame_desc.flags */
+enum {
+    MR_FRAME_SHADOWS = 1,     /* run the shadow-volume stencil pass (obj/core.py:610-622) */
+    MR_FRAME_KEEP_FLOAT = 2,  /* also keep the float32 frame (needed by mr_read_frame_f32) */
+    MR_FRAME_FACE_STATUS = 4  /* also compute the per-face status histogram (obj/core.py:625-636) */
+};
+
+typedef struct mr_scene mr_scene;
+
+/* Per-frame constants: what Scene.render() derives from camera / debug_camera / light /
+ * resolution before its loops (obj/core.py:588-600, 394-429; obj/transformation.py:123-136;
+ * obj/plane_intersection.py:43-56).  The host computes them in float64. */
+typedef struct mr_frame_desc {
+    int32_t width, height;          /* Scene.resolution = (height, width) */
+    int32_t system;                 /* SYSTEM.RH = +1, SYSTEM.LH = -1 (obj/constants.py:29-31) */
+    int32_t backface_culling;       /* Camera.backface_culling */
+    int32_t light_type;             /* MR_LIGHT_* */
+    int32_t flags;                  /* MR_FRAME_* */
+    int32_t row_begin, row_end;     /* output rows [row_begin, row_end) this device renders;
+                                       0, height for the whole frame (screen-tile split) */
+    double mvp[16];                 /* camera.MVP */
+    double viewport[16];            /* camera.viewport */
+    double debug_mvp[16];           /* debug_camera.MVP (obj/triangular.py:39) */
+    double frustum_planes[24];      /* camera.frustum_planes: left,right,bottom,top,near,far */
+    double z_near, z_far;           /* camera.near / camera.far */
+    double camera_pos[3];
+    double light_pos[3], light_dir[3], light_color[3], light_ambient[3];
+    double specular_strength;
+    double att_constant, att_linear, att_quadratic;
+    double spot_edge0, spot_edge1;  /* cos(20 deg), cos(10 deg) (obj/triangular.py:158-159) */
+    float background[3];            /* obj/core.py:597-600 */
+    int32_t reserved;
+} mr_frame_desc;
+
+/* One material group of a model (obj/materials.py:47-55; obj/core.py:125). */
+typedef struct mr_material {
+    double kd[3];                   /* Material.Kd */
+    double ks255[3];                /* Material.Ks * 255, evaluated by the host in Ks's dtype (obj/core.py:152) */
+    double ns;                      /* Material.Ns */
+    int32_t tex_kd, tex_norm, tex_ks;  /* ids from mr_scene_add_texture, or -1 */
+    int32_t norm_tangent;           /* normal map is tangent-space (dtype.metadata['tangent']) */
+} mr_material;
+
+/* One Model (obj/core.py:231-251): arrays exactly as Model.load_model leaves them, with
+ * indices already made non-negative. */
+typedef struct mr_model_desc {
+    const double *vertices;         /* (n_vertices, 4) Model.vertices widened to float64 */
+    const float *uv;                /* (n_uv, 3) Model.uv, or NULL */
+    const float *normals;           /* (n_normals, 3) Model.normals, or NULL */
+    const int32_t *faces;           /* (n_faces, 3, 4) Model._faces: [vertex, uv, normal, material] per corner */
+    const mr_material *materials;   /* (n_materials) indexed by the material column */
+    int32_t n_vertices, n_uv, n_normals, n_faces, n_materials;
+    int32_t vertices_are_f32;       /* Model.vertices.dtype == float32: edge vectors and the silhouette
+                                       normal are then formed in float32 like NumPy does */
+    int32_t clip;                   /* Model.clip */
+    int32_t depth_test;             /* Model.depth_test (0 is MR_E_UNSUPPORTED) */
+} mr_model_desc;
+
+/* Counters of the last mr_render call (BASELINE.md fragment definition). */
+typedef struct mr_stats {
+    int64_t frag_tri;               /* (triangle, pixel) pairs with u,v,w >= 0 (obj/triangular.py:78) */
+    int64_t frag_quad;              /* (shadow quad, pixel) pairs inside the quad (obj/triangular.py:347) */
+    int64_t covered_px;             /* pixels with a z-buffer winner */
+    int64_t lit_px;                 /* covered pixels with stencil == 0 */
+    int64_t stencil_updates;        /* quad fragments that passed the z test */
+    int64_t n_faces, n_faces_setup; /* faces in the scene / faces that produced a pixel box */
+    int64_t n_quads, n_quads_drawn; /* silhouette edges / quads that reached rasterisation */
+    int64_t tri_bin_entries, quad_bin_entries;   /* (primitive, tile) pairs */
+    float gpu_ms_total;             /* device time of the whole frame (HIP events) */
+    float gpu_ms_geometry;          /* vertex transform + triangle set-up + silhouette + quad set-up */
+    float gpu_ms_binning;
+    float gpu_ms_raster;            /* tile visibility kernel (coverage, z, stencil) */
+    float gpu_ms_shade;             /* deferred shading + finalise */
+    float gpu_ms_copy;              /* device -> host copy of the uint8 frame */
+} mr_stats;
+
+/* Selects the HIP device for the calling process (one process per GPU) and creates the
+ * library's stream.  device < 0 keeps the current device. */
+int mr_init(int device);
+
+/* 1 when a HIP device is visible, else 0.  Never fails. */
+int mr_device_available(void);
+
+int mr_abi_version(void);
+
+/* Scene() -- obj/core.py:563-582.  Returns NULL on failure. */
+mr_scene *mr_scene_create(void);
+void mr_scene_destroy(mr_scene *scene);
+
+/* Model.textures.register / parse_mtl texture load (obj/core.py:90-105, 334-342): uploads a
+ * float32 (h, w, 3) image exactly as the reference stores it.  Returns the texture id (>= 0)
+ * or a negative error. */
+int mr_scene_add_texture(mr_scene *scene, const float *rgb, int32_t h, int32_t w);
+
+/* Scene.add_model (obj/core.py:584-585).  Returns the model index (>= 0) or a negative error. */
+int mr_scene_add_model(mr_scene *scene, const mr_model_desc *model);
+
+/* Drops all models and textures (keeps device allocations for reuse). */
+int mr_scene_clear(mr_scene *scene);
+
+/* Scene.render() -- obj/core.py:587-640: depth/ambient pass, shadow-volume stencil pass, lit
+ * pass and finalise (flip, **0.8, *255, uint8) on the GPU.  out_rgb receives
+ * (row_end - row_begin) x width x 3 bytes, row 0 = top row of the band.  stats may be NULL. */
+int mr_render(mr_scene *scene, const mr_frame_desc *frame, uint8_t *out_rgb, mr_stats *stats);
+
+/* Same, but leaves the uint8 band in device memory at d_out_rgb (a device pointer owned by
+ * the caller, e.g. a torch tensor's data_ptr) and does not synchronise the host: work is
+ * enqueued on `stream` (a hipStream_t; NULL = the library's own stream).  Used by the
+ * multi-GPU path, which all-gathers the bands with RCCL. */
+int mr_render_device(mr_scene *scene, const mr_frame_desc *frame, void *d_out_rgb, void *stream);
+
+/* Counters / timings of the last mr_render on this scene. */
+int mr_get_stats(mr_scene *scene, mr_stats *stats);
+
+/* Debug taps for parity tests: the reference's working buffers after the last render
+ * (obj/core.py:588-591).  Row = screen y (not flipped), as in the reference. */
+int mr_read_z(mr_scene *scene, double *out_hw);            /* z_buffer, float64 (H, W) */
+int mr_read_stencil(mr_scene *scene, int16_t *out_hw);     /* stencil_buffer, int16 (H, W) */
+int mr_read_winner(mr_scene *scene, int32_t *out_hw);      /* face that owns each pixel, -1 = none */
+int mr_read_frame_f32(mr_scene *scene, float *out_hw3);    /* float frame before finalise (needs MR_FRAME_KEEP_FLOAT) */
+int mr_read_face_status(mr_scene *scene, uint8_t *out_faces);  /* MR_FACE_* per face (needs MR_FRAME_FACE_STATUS) */
+/* Silhouette edges of the last frame as (model, a, b) triples, oriented like the entries of
+ * the reference's model.silhouette (obj/triangular.py:294-302).  Returns the number of edges
+ * (may exceed cap; only cap are written) or a negative error. */
+int mr_read_silhouette(mr_scene *scene, int32_t *out_triples, int32_t cap);
+
+/* Human-readable description of the last error on this thread ("" if none). */
+const char *mr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RAST_H */

@@ -1,0 +1,357 @@
+"""Scene API: ``Model / Camera / Light / Scene`` with ``Scene.render() -> uint8 (H, W, 3)``.
+
+Drop-in for the classes of the reference's ``obj/core.py`` (Model :231, Camera :432,
+Light :444, Scene :558): same constructor arguments, same attribute names, same OBJ/MTL
+ingest rules.  What differs is where the work happens: ``Scene.render`` packs the scene into
+flat arrays (``_pack.py``) and hands it to the HIP library through the C ABI declared in
+``include/mi355rast.h``; nothing is rasterised or shaded on the host.
+"""
+import os
+from functools import cached_property
+from typing import Iterable, List
+
+import numpy as np
+from PIL import Image
+
+from . import _fp
+from .constants import *  # noqa: F401,F403  (re-exported like the reference's core module)
+from .constants import PROJECTION_TYPE, SUBSYSTEM, SYSTEM, mat3x3
+from .lightning import Lightning
+from .materials import Material
+from .transformation import (ViewPort, look_at_rotate_lh, look_at_rotate_rh, looka_at_translate,
+                             normalize, perspectives, scale)
+
+
+def triangulate_int(polygon):
+    """Fan triangulation of one parsed ``f`` record (reference: ``obj/core.py:72-74``)."""
+    for i in range(1, len(polygon) - 1):
+        yield np.array([polygon[0], polygon[i], polygon[i + 1]], dtype=np.int32)
+
+
+class TextureMaps:
+    """``model.textures.register(kind, path, normalize=True, tangent=False)``
+    (reference: ``obj/core.py:77-105``)."""
+
+    texture_map = {
+        "diffuse": "map_Kd",
+        "ambient": "map_Ka",
+        "specular": "map_Ks",
+        "shininess": "map_Ns",
+        "transparency": "map_d",
+        "normals": "norm",
+    }
+
+    def __init__(self, model):
+        self.model = model
+
+    def register(self, attr_name, path, normalize=True, tangent=False):
+        key = self.texture_map.get(attr_name)
+        if key is None:
+            raise ValueError(f"{attr_name} not recognized.\nSupported: {self.texture_map.keys()}")
+        texels = self.load_texture(path)
+        if normalize:                       # [0,1] -> [-1,1]: meant for normal maps, and the default
+            texels = texels * 2 - 1
+        tagged = np.dtype(np.float32, metadata={"tangent": tangent})
+        setattr(self.model.materials["default"], key, np.array(texels, dtype=tagged))
+        self.model._revision += 1
+
+    @staticmethod
+    def load_texture(name):
+        with Image.open(name) as img:
+            return np.asarray(img.convert("RGB")) / 255
+
+
+class Model:
+    """Triangle mesh: ``vertices`` (V,4), ``uv`` (T,3), ``normals`` (N,3) and ``_faces``
+    (F,3,4) holding per corner ``[vertex, uv, normal, material-group]`` indices."""
+
+    def __init__(self, vertices, uv, normals, faces, shadowing=False, materials=None,
+                 material_group=None, clip=True, depth_test=True):
+        self.vertices = vertices
+        self.uv = uv
+        self.normals = normals
+        self._faces = faces
+        self.shadowing = shadowing          # kept for signature parity; the reference never reads it
+        self.clip = clip
+        self.depth_test = depth_test
+        self.materials = materials or {"default": Material()}
+        self.material_group = material_group or ["default"]
+        self.textures = TextureMaps(self)
+        self.shape = None
+        self.silhouette = set()             # filled by Scene.render with the last frame's edges
+        self._revision = 0                  # bumped whenever device copies go stale
+
+    # -- ingest ---------------------------------------------------------------------------
+    @classmethod
+    def load_model(cls, name, shadowing=True):
+        """Parse a Wavefront OBJ (reference: ``obj/core.py:257-318``).
+
+        ``v`` gets ``w = 1`` appended, 2-component ``vt`` is padded with 0, polygons are
+        fan-triangulated, a missing index (``1//3``) becomes -1, positive indices become
+        0-based and negative ones are left as they are (NumPy-relative)."""
+        verts, uvs, norms, tris = [], [], [], []
+        groups = ["default"]
+        current = "default"
+        materials = {"default": Material()}
+        folder = os.path.dirname(name)
+        with open(name) as fh:
+            for line in fh:
+                tag, _, rest = line.partition(" ")
+                if tag == "v":
+                    xyz = rest.split()
+                    verts.append(xyz + [1] if len(xyz) == 3 else xyz)
+                elif tag == "vt":
+                    st = rest.split()
+                    uvs.append(st + [0] if len(st) == 2 else st)
+                elif tag == "vn":
+                    norms.append(rest.split())
+                elif tag == "f":
+                    group_id = groups.index(current) + 1
+                    corners = [[(ref if ref != "" else -1) for ref in corner.split("/")] + [group_id]
+                               for corner in rest.split()]
+                    tris.extend(triangulate_int(corners))
+                elif tag == "usemtl":
+                    current = rest.split()[0]
+                    if current not in groups:
+                        groups.append(current)
+                elif tag == "mtllib":
+                    lib = os.path.join(folder, rest.split()[0])
+                    if os.path.exists(lib):
+                        materials.update(cls.parse_mtl(lib))
+        faces = np.array(tris)
+        faces = np.where(faces > 0, faces - 1, faces)
+        return cls(np.array(verts, dtype=np.float32),
+                   np.array(uvs, dtype=np.float32) if uvs else None,
+                   np.array(norms, dtype=np.float32) if norms else None,
+                   faces, shadowing, materials=materials, material_group=groups)
+
+    @staticmethod
+    def parse_mtl(mtllib):
+        """``.mtl`` -> {name: Material}; ``map*``/``disp`` keys load the image next to the
+        library, ``map_bump`` is stored as a tangent-space ``norm`` (``obj/core.py:321-348``)."""
+        library = {}
+        folder = os.path.dirname(mtllib)
+        material = None
+        with open(mtllib) as fh:
+            for line in fh:
+                if line.startswith("#") or line == "\n":
+                    continue
+                key, *val = line.split()
+                if key == "newmtl":
+                    material = library[val[0]] = Material()
+                elif key.startswith("map") or key == "disp":
+                    path = os.path.join(folder, val[0])
+                    if not os.path.exists(path):
+                        print(f"{key} {path} is not found. Recommend manually assign texture by descriptor "
+                              f"Model.texture.register")
+                        continue
+                    dtype = np.float32
+                    if key == "map_bump":
+                        key, dtype = "norm", np.dtype(np.float32, metadata={"tangent": True})
+                    setattr(material, key, np.array(TextureMaps.load_texture(path), dtype=dtype))
+                else:
+                    setattr(material, key, val)
+        return library
+
+    def __matmul__(self, other):
+        self.vertices = self.vertices @ other
+        self._revision += 1
+        return self
+
+    def face_material(self, group_index):
+        """Material of a face whose first corner carries *group_index* (``obj/core.py:125``)."""
+        return self.materials.get(self.material_group[group_index], self.materials["default"])
+
+
+class PositionedObject:
+    def __init__(self, position, center=np.array([0, 0, 0])):
+        self.scene = None
+        self.position = position
+        self.center = center
+
+    @property
+    def direction(self):
+        return normalize(self.position - self.center).ravel()
+
+    def direction_to(self, other):
+        return normalize(self.direction - other)
+
+    def set_position(self, new_position):
+        self.position = new_position
+        return self
+
+
+class TransformationMatrixMixin:
+    """View / projection matrices of a positioned object (``obj/core.py:373-429``).
+
+    ``lookat`` and ``MVP`` are cached on first use, as in the reference.  The 4x4 products
+    use explicit fma chains (``_fp.matmul_chain``) so the constants handed to the device are
+    the same on every host."""
+
+    def __init__(self, x_offset=0, y_offset=0, projection_type=PROJECTION_TYPE.PERSPECTIVE,
+                 up=np.array([0, 1, 0]), near=0.001, far=6, fovy=90):
+        self.up = up
+        self.projection_type = projection_type
+        self.near = (np.linalg.norm(self.position)
+                     if projection_type == PROJECTION_TYPE.ORTHOGRAPHIC else near)
+        self.far = far
+        self.fovy = fovy
+        self.x_offset = x_offset
+        self.y_offset = y_offset
+        self.scene = None
+
+    @property
+    def projection(self):
+        height, width = self.scene.resolution
+        build = perspectives[self.scene.subsystem][self.projection_type][self.scene.system]
+        return build(self.fovy, width / height, self.near, self.far)
+
+    @property
+    def rotate(self):
+        # argument order (center, position) is the reference's: the camera looks along -forward
+        if self.scene.system == SYSTEM.LH:
+            return look_at_rotate_lh(self.center, self.position, self.up)
+        return look_at_rotate_rh(self.center, self.position, self.up)
+
+    @property
+    def translate(self):
+        return looka_at_translate(self.position)
+
+    @cached_property
+    def lookat(self):
+        return _fp.matmul_chain(self.translate, self.rotate)
+
+    @cached_property
+    def MVP(self):
+        return _fp.matmul_chain(self.lookat, self.projection)
+
+    @property
+    def frustum_planes(self):
+        from .plane_intersection import extract_frustum_planes
+        return extract_frustum_planes(self.MVP)
+
+    @property
+    def viewport(self):
+        return ViewPort(self.scene.resolution, self.far, self.near,
+                        x_offset=self.x_offset, y_offset=self.y_offset)
+
+
+class Camera(PositionedObject, TransformationMatrixMixin):
+    def __init__(self, position, center, show=False, backface_culling=True, **kwargs):
+        PositionedObject.__init__(self, np.array(position), center)
+        TransformationMatrixMixin.__init__(self, **kwargs)
+        self.show = show
+        self.backface_culling = backface_culling
+
+
+class Light(PositionedObject, TransformationMatrixMixin):
+    """Point / directional / spot light with the reference's attenuation model
+    ``1 / (constant + d (linear + quadratic d))`` (``obj/core.py:444-524``)."""
+
+    def __init__(self, position, light_type=Lightning.POINT_LIGHTNING, center=(0, 0, 0),
+                 color=(1., 1., 1.), ambient_strength=0, diffuse=1, specular_strength=0.5,
+                 show=False, constant=1, linear=0.14, quadratic=0.07, **kwargs):
+        self.color = np.array(color)
+        self.light_type = light_type
+        PositionedObject.__init__(self, np.array(position), np.array(center))
+        self.ambient = ambient_strength * self.color
+        self.show = show
+        self.diffuse = diffuse
+        self.specular_strength = specular_strength
+        self.constant = constant
+        self.linear = linear
+        self.quadratic = quadratic
+        TransformationMatrixMixin.__init__(self, **kwargs)
+
+    @staticmethod
+    def reflect(I, N):
+        return normalize(I - 2. * (N * I).sum(axis=1)[..., np.newaxis] * N)
+
+    @staticmethod
+    def smoothstep(edge0, edge1, x_array):
+        t = np.clip((x_array - edge0) / (edge1 - edge0), 0.0, 1.0)
+        return t * t * (3 - 2 * t)
+
+    def attenuation(self, fragment_position):
+        d = np.linalg.norm(self.position - fragment_position, axis=1)
+        return 1.0 / (self.constant + d * (self.linear + self.quadratic * d))[..., np.newaxis]
+
+
+class Bound:
+    """Descriptor tying a camera / light to the scene it is assigned to
+    (``obj/core.py:527-555``).  State is kept per scene instance (the reference keeps it on
+    the descriptor, so all its scenes share the last assignment)."""
+
+    def __set_name__(self, owner, name):
+        self._slot = "_bound_" + name
+
+    def __set__(self, instance, value):
+        instance.__dict__[self._slot] = value
+        if value is None:
+            return
+        value.scene = instance
+        if getattr(value, "show", False):
+            raise NotImplementedError(
+                "show=True gizmos need sphere.obj / camera.obj, which the reference does not ship")
+
+    def __get__(self, instance, owner):
+        if instance is None:
+            return self
+        return instance.__dict__.get(self._slot)
+
+
+class Scene:
+    """``Scene(camera, light, shadows, debug_camera, resolution=(H, W), system, subsystem,
+    skymap)`` -- reference ``obj/core.py:558-640``.
+
+    * ``debug_camera`` also clips fragments, exactly as in the reference
+      (``obj/triangular.py:39,83``); ``None`` means "same as ``camera``" (the reference raises).
+    * ``shadows`` is accepted and ignored like upstream (``obj/core.py:568``): the stencil
+      pass always runs.  Use ``render(shadows=False)`` to skip it explicitly.
+    """
+
+    camera = Bound()
+    light = Bound()
+    debug_camera = Bound()
+
+    def __init__(self, camera=None, light=None, shadows=False, debug_camera=None,
+                 resolution=(1500, 1500), system=SYSTEM.RH, subsystem=SUBSYSTEM.DIRECTX,
+                 skymap=None, device=None):
+        self.system = system
+        self.subsystem = subsystem
+        self.models: List[Model] = []
+        self.camera = camera if camera is not None else Camera(position=(0, 0, 1), center=(0, 0, 0))
+        self.light = light if light is not None else Light(position=(1, 1, 1))
+        self.debug_camera = debug_camera
+        self.resolution = resolution
+        self.skybox = skymap
+        self.shadows = shadows
+        self.device = device
+        self.draw_debug_frustum = True      # the reference always overlays it (core.py:638)
+        self._renderer = None
+        self.last_stats = None
+
+    def add_model(self, model):
+        self.models.append(model)
+
+    # -- rendering ------------------------------------------------------------------------
+    def _backend(self):
+        if self._renderer is None:
+            from ._native import DeviceRenderer
+            self._renderer = DeviceRenderer(self.device)
+        return self._renderer
+
+    def render(self, shadows=True, row_band=None):
+        """Render one frame on the GPU and return ``uint8 (H, W, 3)`` (row 0 = top).
+
+        Unlike the reference, repeated calls give the same frame: the silhouette is rebuilt
+        from scratch every frame instead of being toggled in ``model.silhouette``."""
+        backend = self._backend()
+        out = backend.render(self, shadows=shadows, row_band=row_band)
+        self.last_stats = backend.last_stats
+        return out
+
+    def close(self):
+        if self._renderer is not None:
+            self._renderer.close()
+            self._renderer = None

@@ -1,0 +1,246 @@
+"""Scene recipes shared by the golden-vector generator and the tests.
+
+Every recipe is written against an ``api`` namespace exposing the reference's public names
+(``Model, Camera, Light, Scene, Lightning, SYSTEM, SUBSYSTEM, scale, translation,
+rotate_xyz``).  ``tests/golden/make_golden.py`` passes the reference's own modules (build
+container only); the tests pass ``py_numpy_renderer_amd``.  Both therefore construct the
+same scenes from the same files, which is what makes the captured buffers golden vectors.
+
+Recipes follow SURVEY.md section 8(d): camera (0.5,1,2)->origin fovy 60 near 0.1 far 20, a debug
+camera with identical arguments, point light (2,3,4) ambient 0.1 specular 0.1, RH/DirectX.
+"""
+import math
+import os
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ASSETS = os.path.join(HERE, "assets")
+GENERATED = os.path.join(tempfile.gettempdir(), "mi355rast_generated")
+
+
+def product_api():
+    """The product's host API as a recipe namespace."""
+    import py_numpy_renderer_amd as pkg
+    from py_numpy_renderer_amd import transformation as tr
+    return SimpleNamespace(Model=pkg.Model, Camera=pkg.Camera, Light=pkg.Light, Scene=pkg.Scene,
+                           Lightning=pkg.Lightning, SYSTEM=pkg.SYSTEM, SUBSYSTEM=pkg.SUBSYSTEM,
+                           scale=tr.scale, translation=tr.translation, rotate_xyz=tr.rotate_xyz)
+
+
+# --------------------------------------------------------------------------- generated meshes
+def _write_if_changed(path, text):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    if os.path.exists(path):
+        with open(path) as fh:
+            if fh.read() == text:
+                return path
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as fh:
+        fh.write(text)
+    os.replace(tmp, path)
+    return path
+
+
+def floor_obj():
+    """Two triangles (+-2, -1, +-2), normal +y (upstream's floor.obj is not shipped)."""
+    text = ("v -2 -1 -2\nv 2 -1 -2\nv 2 -1 2\nv -2 -1 2\n"
+            "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 1 0\n"
+            "f 1/1/1 3/3/1 2/2/1\nf 1/1/1 4/4/1 3/3/1\n")
+    return _write_if_changed(os.path.join(GENERATED, "floor.obj"), text)
+
+
+def torus_obj(nu, nv, R=0.6, r=0.25, tilt_deg=35.0):
+    """Torus with nu x nv cells (2 triangles each), tilted about x; seam duplicated in vt only."""
+    path = os.path.join(GENERATED, f"torus_{nu}x{nv}.obj")
+    if os.path.exists(path):
+        return path
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    u = 2 * np.pi * i / nu
+    v = 2 * np.pi * j / nv
+    ct, st = math.cos(math.radians(tilt_deg)), math.sin(math.radians(tilt_deg))
+
+    def tilt(x, y, z):
+        return x, ct * y - st * z, st * y + ct * z
+
+    px, py, pz = tilt((R + r * np.cos(v)) * np.cos(u), r * np.sin(v) + 0 * u, (R + r * np.cos(v)) * np.sin(u))
+    nx, ny, nz = tilt(np.cos(v) * np.cos(u), np.sin(v) + 0 * u, np.cos(v) * np.sin(u))
+    lines = []
+    for a, b, c in zip(px.ravel(), py.ravel(), pz.ravel()):
+        lines.append("v %.6f %.6f %.6f" % (a, b, c))
+    for ii in range(nu + 1):
+        for jj in range(nv + 1):
+            lines.append("vt %.6f %.6f" % (ii / nu, jj / nv))
+    for a, b, c in zip(nx.ravel(), ny.ravel(), nz.ravel()):
+        lines.append("vn %.6f %.6f %.6f" % (a, b, c))
+
+    def vid(ii, jj):
+        return (ii % nu) * nv + (jj % nv) + 1
+
+    def tid(ii, jj):
+        return ii * (nv + 1) + jj + 1
+
+    for ii in range(nu):
+        for jj in range(nv):
+            a = (ii, jj); b = (ii + 1, jj); c = (ii + 1, jj + 1); d = (ii, jj + 1)
+            for tri in ((a, c, b), (a, d, c)):
+                lines.append("f " + " ".join("%d/%d/%d" % (vid(*p), tid(*p), vid(*p)) for p in tri))
+    return _write_if_changed(path, "\n".join(lines) + "\n")
+
+
+def bare_tetra_obj():
+    """Tetrahedron with uv but no normals (``v/vt/``): exercises the face-normal shading path."""
+    text = ("v 0 0.6 0\nv -0.5 -0.3 0.4\nv 0.5 -0.3 0.4\nv 0 -0.3 -0.5\n"
+            "vt 0 0\nvt 1 0\nvt 0.5 1\n"
+            "f 1/1/ 2/2/ 3/3/\nf 1/1/ 3/2/ 4/3/\nf 1/1/ 4/2/ 2/3/\nf 2/1/ 4/2/ 3/3/\n")
+    return _write_if_changed(os.path.join(GENERATED, "bare_tetra.obj"), text)
+
+
+# --------------------------------------------------------------------------- building blocks
+def _std_cameras(api, **over):
+    kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
+    kw.update(over)
+    return (api.Camera((0.5, 1, 2), (0, 0, 0), **kw), api.Camera((0.5, 1, 2), (0, 0, 0), **kw))
+
+
+def _std_light(api, **over):
+    kw = dict(ambient_strength=0.1, specular_strength=0.1)
+    kw.update(over)
+    return api.Light((2, 3, 4), **kw)
+
+
+def _diablo(api):
+    d = os.path.join(ASSETS, "diablo3_pose")
+    m = api.Model.load_model(os.path.join(d, "diablo3_pose.obj"))
+    m.textures.register("normals", os.path.join(d, "diablo3_pose_nm_tangent.tga"), tangent=True)
+    m.textures.register("diffuse", os.path.join(d, "diablo3_pose_diffuse.tga"), normalize=False)
+    return m
+
+
+def _floor(api, textured=True):
+    m = api.Model.load_model(floor_obj())
+    if textured:
+        m.textures.register("diffuse", os.path.join(ASSETS, "floor_diffuse.tga"), normalize=False)
+    return m
+
+
+def _torus(api, nu, nv):
+    m = api.Model.load_model(torus_obj(nu, nv))
+    m.textures.register("diffuse", os.path.join(ASSETS, "grid.tga"), normalize=False)
+    m.textures.register("normals", os.path.join(ASSETS, "floor_nm_tangent.tga"), tangent=True)
+    return m
+
+
+def _scene(api, cam, dbg, light, resolution, models, **kw):
+    sc = api.Scene(cam, light, debug_camera=dbg, resolution=resolution, **kw)
+    for m in models:
+        sc.add_model(m)
+    return sc
+
+
+# --------------------------------------------------------------------------- recipes
+def cube_small(api, resolution=(120, 160)):
+    """G1: cube.obj with .mtl (map_Kd, map_Ks, Ns 32), point light."""
+    cam, dbg = _std_cameras(api)
+    cube = api.Model.load_model(os.path.join(ASSETS, "cube", "cube.obj"))
+    return _scene(api, cam, dbg, _std_light(api), resolution, [cube])
+
+
+def cube_outward(api, resolution=(120, 160)):
+    """Cube with normals flipped outward (lit faces show the specular map) and f64 vertices
+    (``Model @ scale`` promotes float32 vertices to float64)."""
+    cam, dbg = _std_cameras(api)
+    cube = api.Model.load_model(os.path.join(ASSETS, "cube", "cube.obj"))
+    cube.normals = -cube.normals
+    cube = cube @ api.scale(0.45)
+    floor = _floor(api, textured=False)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [cube, floor])
+
+
+def diablo_small(api, resolution=(240, 320)):
+    """G2: diablo, tangent-space normal map, shadows onto itself."""
+    cam, dbg = _std_cameras(api)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [_diablo(api)])
+
+
+def diablo_floor_lh_gl(api, resolution=(270, 480)):
+    """G3: upstream main.py's parameters (obj/main.py:63-92,117-129): LH/OpenGL, directional light
+    (w=2 extrusion), culling off, and a debug camera that really clips."""
+    light = api.Light((5, 5, 0), light_type=api.Lightning.DIRECTIONAL_LIGHTNING, center=(0, 0.5, 0.5),
+                      fovy=90, linear=0.000000001, quadratic=0.0000000001,
+                      ambient_strength=0.1, specular_strength=0.1)
+    cam = api.Camera((0.5, 3, 5), up=np.array((0, 1, 0)), fovy=90, near=0.0001, far=400,
+                     backface_culling=False, center=(0, 0, 0))
+    dbg = api.Camera((0, 3, 0.01), up=np.array((0, 1, 0)), fovy=80, near=1, far=3,
+                     backface_culling=True, center=(0, 0, 0))
+    return _scene(api, cam, dbg, light, resolution, [_diablo(api), _floor(api)],
+                  system=api.SYSTEM.LH, subsystem=api.SUBSYSTEM.OPENGL)
+
+
+def diablo_floor(api, resolution=(270, 480)):
+    """c3 at reduced size: diablo + floor, RH/DirectX, point light, shadows."""
+    cam, dbg = _std_cameras(api)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [_diablo(api), _floor(api)])
+
+
+def torus_spot(api, resolution=(180, 320), nu=40, nv=25):
+    """G4: 2 000-triangle torus + floor under a spot light."""
+    cam, dbg = _std_cameras(api)
+    light = api.Light((2, 3, 4), light_type=api.Lightning.SPOT_LIGHTNING,
+                      ambient_strength=0.1, specular_strength=0.1)
+    return _scene(api, cam, dbg, light, resolution, [_torus(api, nu, nv), _floor(api)])
+
+
+def torus_floor(api, resolution=(1080, 1920), nu=500, nv=200):
+    """c4 (nu=500, nv=200 -> 200 000 triangles) and its reduced variants."""
+    cam, dbg = _std_cameras(api)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [_torus(api, nu, nv), _floor(api)])
+
+
+def tetra_bare(api, resolution=(120, 160)):
+    """Model without vertex normals and without textures on a textured floor: Kd colour,
+    face-normal shading, GL/RH projection."""
+    cam, dbg = _std_cameras(api)
+    tet = api.Model.load_model(bare_tetra_obj())
+    return _scene(api, cam, dbg, _std_light(api), resolution, [tet, _floor(api)],
+                  system=api.SYSTEM.RH, subsystem=api.SUBSYSTEM.OPENGL)
+
+
+def diablo_closeup(api, resolution=(200, 200)):
+    """Camera close enough that triangles cross the frustum sides: exercises the per-fragment
+    clip (obj/triangular.py:80-87) and screen-edge bounding boxes."""
+    kw = dict(fovy=40, near=0.3, far=5, backface_culling=True)
+    cam = api.Camera((0.2, 0.5, 0.9), (0, 0.3, 0), **kw)
+    dbg = api.Camera((0.2, 0.5, 0.9), (0, 0.3, 0), **kw)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [_diablo(api)])
+
+
+# name -> (builder, kwargs); the small ones have full golden buffers committed
+SMALL = {
+    "cube_small": (cube_small, {}),
+    "cube_outward": (cube_outward, {}),
+    "diablo_small": (diablo_small, {}),
+    "diablo_floor_lh_gl": (diablo_floor_lh_gl, {}),
+    "diablo_floor_small": (diablo_floor, {}),
+    "torus_spot": (torus_spot, {}),
+    "tetra_bare": (tetra_bare, {}),
+    "diablo_closeup": (diablo_closeup, {}),
+}
+
+# BASELINE.json configs at full size: only the uint8 frame, winner map, stencil and z row sums are kept
+FULL = {
+    "c2_diablo_1080p": (diablo_small, {"resolution": (1080, 1920)}),       # rendered with shadows off
+    "c3_diablo_floor_1080p": (diablo_floor, {"resolution": (1080, 1920)}),
+    "c4_torus200k_1080p": (torus_floor, {"resolution": (1080, 1920), "nu": 500, "nv": 200}),
+}
+NO_SHADOW = {"c2_diablo_1080p", "diablo_small_noshadow"}
+
+
+def build(api, name):
+    if name == "diablo_small_noshadow":
+        return diablo_small(api)
+    fn, kw = {**SMALL, **FULL}[name]
+    return fn(api, **kw)
