@@ -1,0 +1,252 @@
+"""ctypes binding of ``libmi355rast.so`` (C ABI: ``include/mi355rast.h``).
+
+``DeviceRenderer`` is what ``Scene.render`` talks to: it mirrors the scene into the
+library (re-uploading only when a model or texture changed), fills the per-frame constant
+block and calls ``mr_render``.  There is no CPU fallback: if the library is missing or no
+GPU is visible the calls raise ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._pack import pack_frame, pack_model
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmi355rast.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+MR_OK = 0
+MR_E_OVERFLOW = -4
+FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS = 1, 2, 4
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("system", C.c_int32),
+                ("backface_culling", C.c_int32), ("light_type", C.c_int32), ("flags", C.c_int32),
+                ("row_begin", C.c_int32), ("row_end", C.c_int32),
+                ("mvp", C.c_double * 16), ("viewport", C.c_double * 16), ("debug_mvp", C.c_double * 16),
+                ("frustum_planes", C.c_double * 24), ("z_near", C.c_double), ("z_far", C.c_double),
+                ("camera_pos", C.c_double * 3), ("light_pos", C.c_double * 3), ("light_dir", C.c_double * 3),
+                ("light_color", C.c_double * 3), ("light_ambient", C.c_double * 3),
+                ("specular_strength", C.c_double), ("att_constant", C.c_double), ("att_linear", C.c_double),
+                ("att_quadratic", C.c_double), ("spot_edge0", C.c_double), ("spot_edge1", C.c_double),
+                ("background", C.c_float * 3), ("reserved", C.c_int32)]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("kd", C.c_double * 3), ("ks255", C.c_double * 3), ("ns", C.c_double),
+                ("tex_kd", C.c_int32), ("tex_norm", C.c_int32), ("tex_ks", C.c_int32),
+                ("norm_tangent", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("uv", C.c_void_p), ("normals", C.c_void_p), ("faces", C.c_void_p),
+                ("materials", C.POINTER(MaterialDesc)),
+                ("n_vertices", C.c_int32), ("n_uv", C.c_int32), ("n_normals", C.c_int32),
+                ("n_faces", C.c_int32), ("n_materials", C.c_int32),
+                ("vertices_are_f32", C.c_int32), ("clip", C.c_int32), ("depth_test", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = ([(n, C.c_int64) for n in (
+        "frag_tri", "frag_quad", "covered_px", "lit_px", "stencil_updates", "n_faces", "n_faces_setup",
+        "n_quads", "n_quads_drawn", "tri_bin_entries", "quad_bin_entries")] +
+        [(n, C.c_float) for n in ("gpu_ms_total", "gpu_ms_geometry", "gpu_ms_binning", "gpu_ms_raster",
+                                  "gpu_ms_shade", "gpu_ms_copy")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/mi355rast.h declares: (restype, argtypes)
+_PROTOTYPES = {
+    "mr_init": (C.c_int, [C.c_int]),
+    "mr_device_available": (C.c_int, []),
+    "mr_abi_version": (C.c_int, []),
+    "mr_scene_create": (C.c_void_p, []),
+    "mr_scene_destroy": (None, [C.c_void_p]),
+    "mr_scene_add_texture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "mr_scene_add_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
+    "mr_scene_clear": (C.c_int, [C.c_void_p]),
+    "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "mr_render_device": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p]),
+    "mr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "mr_read_z": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mr_read_stencil": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mr_read_winner": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mr_read_frame_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mr_read_face_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mr_read_silhouette": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "mr_last_error": (C.c_char_p, []),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library; raises RuntimeError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        msg = load_library().mr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+    return rc
+
+
+def fill_frame_desc(pf, row_band=None, keep_float=False):
+    d = FrameDesc()
+    d.width, d.height, d.system = pf.width, pf.height, pf.system
+    d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
+    d.flags = (FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
+    d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
+    for name in ("mvp", "viewport", "debug_mvp", "frustum_planes", "camera_pos", "light_pos", "light_dir",
+                 "light_color", "light_ambient"):
+        dst = getattr(d, name)
+        for i, v in enumerate(np.asarray(getattr(pf, name), dtype=np.float64).ravel()):
+            dst[i] = v
+    d.z_near, d.z_far = pf.z_near, pf.z_far
+    d.specular_strength = pf.specular_strength
+    d.att_constant, d.att_linear, d.att_quadratic = pf.att_constant, pf.att_linear, pf.att_quadratic
+    d.spot_edge0, d.spot_edge1 = pf.spot_edge0, pf.spot_edge1
+    for i in range(3):
+        d.background[i] = float(pf.background[i])
+    return d
+
+
+class DeviceRenderer:
+    """Owns one ``mr_scene`` handle and keeps it in step with a Python ``Scene``."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        _check(self.lib.mr_init(-1 if device is None else int(device)), "mr_init")
+        self.handle = self.lib.mr_scene_create()
+        if not self.handle:
+            raise RuntimeError("mr_scene_create failed: " + self.lib.mr_last_error().decode())
+        self._signature = None
+        self.last_stats = None
+        self._frame = None
+
+    # -- scene upload ---------------------------------------------------------------------
+    @staticmethod
+    def _scene_signature(scene):
+        return tuple((id(m), m._revision, id(m.vertices), id(m._faces), id(m.uv), id(m.normals),
+                      bool(m.clip), bool(m.depth_test)) for m in scene.models)
+
+    def sync_scene(self, scene):
+        sig = self._scene_signature(scene)
+        if sig == self._signature:
+            return
+        _check(self.lib.mr_scene_clear(self.handle), "mr_scene_clear")
+        textures, seen, uploaded = [], {}, 0
+        for model in scene.models:
+            pm = pack_model(model, textures, seen)
+            for tex in textures[uploaded:]:
+                _check(self.lib.mr_scene_add_texture(self.handle, tex.ctypes.data, tex.shape[0], tex.shape[1]),
+                       "mr_scene_add_texture")
+            uploaded = len(textures)
+            mats = (MaterialDesc * len(pm.materials))()
+            for j, m in enumerate(pm.materials):
+                for i in range(3):
+                    mats[j].kd[i], mats[j].ks255[i] = m.kd[i], m.ks255[i]
+                mats[j].ns = m.ns
+                mats[j].tex_kd, mats[j].tex_norm, mats[j].tex_ks = m.tex_kd, m.tex_norm, m.tex_ks
+                mats[j].norm_tangent = int(m.norm_tangent)
+            d = ModelDesc()
+            d.vertices = pm.vertices.ctypes.data
+            d.uv = pm.uv.ctypes.data if pm.uv is not None else None
+            d.normals = pm.normals.ctypes.data if pm.normals is not None else None
+            d.faces = pm.faces.ctypes.data
+            d.materials = mats
+            d.n_vertices = len(pm.vertices)
+            d.n_uv = 0 if pm.uv is None else len(pm.uv)
+            d.n_normals = 0 if pm.normals is None else len(pm.normals)
+            d.n_faces, d.n_materials = len(pm.faces), len(pm.materials)
+            d.vertices_are_f32, d.clip, d.depth_test = int(pm.vertices_are_f32), int(pm.clip), int(pm.depth_test)
+            _check(self.lib.mr_scene_add_model(self.handle, C.byref(d)), "mr_scene_add_model")
+        self._signature = sig
+
+    # -- frames ---------------------------------------------------------------------------
+    def render(self, scene, shadows=True, row_band=None, keep_float=False):
+        """``mr_render``: returns the uint8 band ``(rows, W, 3)`` as a NumPy array."""
+        self.sync_scene(scene)
+        pf = pack_frame(scene, shadows)
+        desc = fill_frame_desc(pf, row_band, keep_float)
+        rows = desc.row_end - desc.row_begin
+        out = np.empty((rows, pf.width, 3), dtype=np.uint8)
+        stats = Stats()
+        _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats)), "mr_render")
+        self.last_stats = stats.as_dict()
+        self._frame = (pf.height, pf.width)
+        return out
+
+    def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None):
+        """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
+        self.sync_scene(scene)
+        pf = pack_frame(scene, shadows)
+        desc = fill_frame_desc(pf, row_band, False)
+        _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
+                                         C.c_void_p(stream_ptr)), "mr_render_device")
+        self._frame = (pf.height, pf.width)
+        self._desc = desc
+        return desc
+
+    def enqueue(self, desc, d_out_ptr, stream_ptr=0):
+        """Re-issue a prepared frame descriptor (no Python-side packing in the timed loop)."""
+        _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
+                                         C.c_void_p(stream_ptr)), "mr_render_device")
+
+    def stats(self):
+        st = Stats()
+        _check(self.lib.mr_get_stats(self.handle, C.byref(st)), "mr_get_stats")
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
+    # -- debug taps -----------------------------------------------------------------------
+    def _tap(self, fn, dtype, extra=()):
+        h, w = self._frame
+        out = np.empty((h, w) + tuple(extra), dtype=dtype)
+        _check(fn(self.handle, out.ctypes.data), fn.__name__)
+        return out
+
+    def read_z(self):
+        return self._tap(self.lib.mr_read_z, np.float64)
+
+    def read_stencil(self):
+        return self._tap(self.lib.mr_read_stencil, np.int16)
+
+    def read_winner(self):
+        return self._tap(self.lib.mr_read_winner, np.int32)
+
+    def read_frame_f32(self):
+        return self._tap(self.lib.mr_read_frame_f32, np.float32, (3,))
+
+    def read_silhouette(self):
+        n = _check(self.lib.mr_read_silhouette(self.handle, None, 0), "mr_read_silhouette")
+        out = np.empty((max(n, 1), 3), dtype=np.int32)
+        _check(self.lib.mr_read_silhouette(self.handle, out.ctypes.data, n), "mr_read_silhouette")
+        return out[:n]
+
+    def close(self):
+        if self.handle:
+            self.lib.mr_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass

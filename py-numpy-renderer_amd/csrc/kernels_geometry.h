@@ -1,0 +1,314 @@
+// kernels_geometry.h -- per-vertex, per-face and per-silhouette-edge work of one frame.
+//
+//   k_vertex      obj/triangular.py:36-45  (once per unique vertex instead of per face corner)
+//   k_tri_setup   obj/triangular.py:47-78, obj/core.py:127-136, obj/transformation.py:12-43
+//   k_tri_count   how many fragments of a face survive coverage + clip (decides NumPy's
+//                 dot-vs-gemv rounding of z, and the CLIPPED status)
+//   k_silhouette  obj/triangular.py:286-302 + obj/core.py:610-622 + obj/plane_intersection.py:59-86
+//                 + obj/triangular.py:320-340 (extrusion, clip, projection, plane, box)
+#pragma once
+
+#include "rast_math.h"
+
+namespace mr {
+
+__global__ void __launch_bounds__(256)
+k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fc.n_vertices) return;
+    double v[4] = { verts[i * 4 + 0], verts[i * 4 + 1], verts[i * 4 + 2], verts[i * 4 + 3] };
+    VertexOut o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o.clip[j] = row_times_col(v, fc.mvp, j);
+        o.clipd[j] = row_times_col(v, fc.debug_mvp, j);
+    }
+    double depth = 1.0 / o.clip[3];
+    double ndc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ndc[j] = o.clip[j] * depth;
+    o.sx = row_times_col(ndc, fc.viewport, 0);
+    o.sy = row_times_col(ndc, fc.viewport, 1);
+    o.sz = row_times_col(ndc, fc.viewport, 2);
+    o.depth = depth;
+    o.zlin = linearize_z(fc, o.sz);
+    out[i] = o;
+}
+
+// unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130),
+// dotted with light.position (obj/triangular.py:295)
+__device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *a, const double *b,
+                                            const double *c, bool verts_f32)
+{
+    double n[3];
+    if (verts_f32) {
+        float e0[3], e1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            e0[j] = (float)b[j] - (float)a[j];
+            e1[j] = (float)c[j] - (float)a[j];
+        }
+        float cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                        e0[0] * e1[1] - e0[1] * e1[0] };
+        float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+        if (l == 0) l = 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n[j] = (double)(cr[j] / l);
+    } else {
+        double e0[3], e1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { e0[j] = b[j] - a[j]; e1[j] = c[j] - a[j]; }
+        double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                         e0[0] * e1[1] - e0[1] * e1[0] };
+        normalize3(cr, n);
+    }
+    return chain3(n[0], n[1], n[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
+            const double *__restrict__ verts, const VertexOut *__restrict__ vout,
+            TriRec *__restrict__ tris, TriClip *__restrict__ clips, uint8_t *__restrict__ status,
+            uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list, Counters *__restrict__ ctr)
+{
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= fc.n_faces) return;
+    const int32_t *fcx = faces + (size_t)f * 12;
+    const int va = fcx[0], vb = fcx[4], vc = fcx[8];
+    const uint8_t ff = face_flags[f];
+
+    if (fc.flags & MR_FRAME_SHADOWS)
+        lit[f] = faces_light(fc, verts + (size_t)va * 4, verts + (size_t)vb * 4, verts + (size_t)vc * 4,
+                             (ff & FF_VERTS_F32) != 0) ? 1 : 0;
+
+    const VertexOut A = vout[va], B = vout[vb], C = vout[vc];
+
+    // obj/triangular.py:47-48: z of the normalised screen-space normal
+    if (fc.backface_culling) {
+        double e0[3] = { B.sx - A.sx, B.sy - A.sy, B.sz - A.sz };
+        double e1[3] = { C.sx - A.sx, C.sy - A.sy, C.sz - A.sz };
+        double n[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                        e0[0] * e1[1] - e0[1] * e1[0] };
+        double u[3];
+        normalize3(n, u);
+        if (u[2] < 0) { status[f] = FACE_BACK_FACE_CULLING; return; }
+    }
+
+    TriRec t;
+    double xs[3] = { A.sx, B.sx, C.sx }, ys[3] = { A.sy, B.sy, C.sy };
+    if (!bound_box(xs, ys, 3, fc.width, fc.height, t.x0, t.x1, t.y0, t.y1)) {
+        status[f] = FACE_EMPTY_Z;
+        return;
+    }
+    t.ax = A.sx; t.ay = A.sy;
+    t.v0x = B.sx - A.sx; t.v0y = B.sy - A.sy;
+    t.v1x = C.sx - A.sx; t.v1y = C.sy - A.sy;
+    t.d00 = (float)chain2(t.v0x, t.v0y, t.v0x, t.v0y);
+    t.d01 = (float)chain2(t.v0x, t.v0y, t.v1x, t.v1y);
+    t.d11 = (float)chain2(t.v1x, t.v1y, t.v1x, t.v1y);
+    float den = t.d00 * t.d11 - t.d01 * t.d01;
+    if (den == 0) { status[f] = FACE_EMPTY_B; return; }
+    t.inv_den = 1.0f / den;
+    t.zl0 = A.zlin; t.zl1 = B.zlin; t.zl2 = C.zlin;
+    t.dp0 = A.depth; t.dp1 = B.depth; t.dp2 = C.depth;
+    long long box = (long long)(t.x1 - t.x0) * (long long)(t.y1 - t.y0);
+    t.flags = ((ff & FF_CLIP) ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u);
+    t.face = f;
+    status[f] = FACE_OK;
+    if (box <= 0) { status[f] = FACE_CLIPPED; return; }    // no sample inside the box
+    tris[f] = t;
+    if (ff & FF_CLIP) {
+        TriClip cl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cl.clip[0][j] = A.clip[j]; cl.clip[1][j] = B.clip[j]; cl.clip[2][j] = C.clip[j];
+            cl.clipd[0][j] = A.clipd[j]; cl.clipd[1][j] = B.clipd[j]; cl.clipd[2][j] = C.clipd[j];
+        }
+        clips[f] = cl;
+    }
+    uint32_t slot = atomicAdd(&ctr->n_valid_tris, 1u);
+    valid_list[slot] = (uint32_t)f;
+}
+
+// One wavefront per set-up triangle: counts the fragments that survive coverage + clip over
+// the WHOLE frame (not just this device's band), stopping as soon as two are found.
+//   0 -> the reference returns CLIPPED for the face; 1 -> z = bar @ zlin is a dot.
+__global__ void __launch_bounds__(256)
+k_tri_count(const FrameConst fc, const uint32_t *__restrict__ valid_list, TriRec *__restrict__ tris,
+            const TriClip *__restrict__ clips, uint8_t *__restrict__ status, Counters *__restrict__ ctr)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (wave >= (int)ctr->n_valid_tris) return;
+    const int f = (int)valid_list[wave];
+    const TriRec t = tris[f];
+    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    const bool do_clip = (t.flags & TF_CLIP) != 0;
+    const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
+    const long long total = (long long)bw * bh;
+    const long long chunks = (total + WAVE - 1) / WAVE;
+    // start at the 64-sample chunk holding the centroid: a well-shaped triangle is done after it
+    int cx = (int)(t.ax + (t.v0x + t.v1x) * (1.0 / 3.0)), cy = (int)(t.ay + (t.v0y + t.v1y) * (1.0 / 3.0));
+    cx = min(max(cx, t.x0), t.x1 - 1); cy = min(max(cy, t.y0), t.y1 - 1);
+    const long long first = ((long long)(cy - t.y0) * bw + (cx - t.x0)) / WAVE;
+    int found = 0;
+    unsigned int covered = 0;      // fragments before the clip, inside this device's band
+    for (long long c = 0; c < chunks && found < 2; ++c) {
+        long long idx = ((first + c) % chunks) * WAVE + lane;
+        bool ok = idx < total;
+        int px = t.x0 + (int)(idx % bw), py = t.y0 + (int)(idx / bw);
+        float u, v, w;
+        tri_bary(t, (double)px, (double)py, single, u, v, w);
+        ok = ok && u >= 0 && v >= 0 && w >= 0;
+        covered += (unsigned int)__popcll(__ballot(ok && py >= fc.band_y0 && py < fc.band_y1));
+        if (do_clip && __ballot(ok)) {
+            if (ok) {
+                double p[3];
+                persp_bary(t, u, v, w, single, p);
+                ok = inside_clip(p, clips[f].clip) && inside_clip(p, clips[f].clipd);
+            }
+        }
+        found += __popcll(__ballot(ok));
+    }
+    if (lane == 0) {
+        if (found == 0) {
+            // the face never reaches the visibility kernel: account for its fragments here
+            // (the fragment count is taken before the clip, obj/triangular.py:78)
+            status[f] = FACE_CLIPPED;
+            if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
+        } else if (found == 1) {
+            tris[f].flags = t.flags | TF_SINGLE_Z;
+        }
+    }
+}
+
+// plane . point >= 0 (obj/plane_intersection.py:39-40), a 1-D dot of length 4
+__device__ __forceinline__ double plane_dot(const double *P, const double *q)
+{
+    return chain4(P[0], P[1], P[2], P[3], q[0], q[1], q[2], q[3]);
+}
+
+// Sutherland-Hodgman against the six frustum planes, in the reference's order and with its
+// intersection formula p_next + t (p_cur - p_next) (obj/plane_intersection.py:24-36, 59-86).
+__device__ int clip_polygon(const double *planes, double (*poly)[4], int n)
+{
+    double tmp[MAX_POLY][4];
+    for (int pl = 0; pl < 6 && n > 0; ++pl) {
+        const double *P = planes + pl * 4;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const double *cur = poly[i];
+            const double *nxt = poly[(i + 1 == n) ? 0 : i + 1];
+            const bool cv = plane_dot(P, cur) >= 0, nv = plane_dot(P, nxt) >= 0;
+            if (cv && m < MAX_POLY) {
+                for (int j = 0; j < 4; ++j) tmp[m][j] = cur[j];
+                ++m;
+            }
+            if (cv != nv && m < MAX_POLY) {
+                double dir[4];
+                for (int j = 0; j < 4; ++j) dir[j] = cur[j] - nxt[j];
+                double den = plane_dot(P, dir);
+                if (!(fabs(den) < 1e-10)) {
+                    double wgt = -plane_dot(P, nxt) / den;
+                    if (0 <= wgt && wgt <= 1) {
+                        for (int j = 0; j < 4; ++j) tmp[m][j] = nxt[j] + wgt * dir[j];
+                        ++m;
+                    }
+                }
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < 4; ++j) poly[i][j] = tmp[i][j];
+    }
+    return n;
+}
+
+// One thread per unique undirected edge of the scene.  An edge is on the silhouette when an
+// odd number of its incident light-facing faces toggled it; it keeps the orientation of the
+// last such face in face order (set add/discard semantics of obj/triangular.py:294-302).
+__global__ void __launch_bounds__(128)
+k_silhouette(const FrameConst fc, const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
+             const int32_t *__restrict__ faces, const uint8_t *__restrict__ lit, const double *__restrict__ verts,
+             QuadRec *__restrict__ quads, int32_t *__restrict__ sil_edges, uint32_t quad_cap,
+             Counters *__restrict__ ctr)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= fc.n_edges) return;
+    uint32_t cnt = 0, last = 0;
+    for (uint32_t k = edge_offset[e]; k < edge_offset[e + 1]; ++k) {
+        uint32_t inc = edge_inc[k];
+        if (lit[inc >> 2]) { ++cnt; last = inc; }
+    }
+    if (!(cnt & 1u)) return;
+    const int f = (int)(last >> 2), k = (int)(last & 3u), k2 = (k + 1) % 3;
+    const int ia = faces[(size_t)f * 12 + k * 4], ib = faces[(size_t)f * 12 + k2 * 4];
+
+    uint32_t sslot = atomicAdd(&ctr->n_quads, 1u);
+    if (sslot < quad_cap) {
+        sil_edges[sslot * 3 + 0] = f;        // the host maps the face back to its model
+        sil_edges[sslot * 3 + 1] = ia;
+        sil_edges[sslot * 3 + 2] = ib;
+    }
+
+    // extrusion (obj/core.py:612-621): quad = (A, B, D, C)
+    const double *A = verts + (size_t)ia * 4, *B = verts + (size_t)ib * 4;
+    double poly[MAX_POLY][4];
+    for (int j = 0; j < 4; ++j) { poly[0][j] = A[j]; poly[1][j] = B[j]; }
+    if (fc.light_type == MR_LIGHT_POINT) {
+        for (int s = 0; s < 2; ++s) {
+            const double *src = s ? B : A;
+            double *dst = s ? poly[2] : poly[3];
+            double d[4] = { src[0] - fc.light_pos[0], src[1] - fc.light_pos[1], src[2] - fc.light_pos[2],
+                            src[3] - 1.0 };
+            double l = sqrt(((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]);
+            if (l == 0) l = 1;
+            for (int j = 0; j < 4; ++j) dst[j] = src[j] + 1000 * (d[j] / l);
+        }
+    } else {
+        for (int j = 0; j < 3; ++j) {
+            double off = fc.light_dir[j] * -1000;
+            poly[3][j] = A[j] + off;
+            poly[2][j] = B[j] + off;
+        }
+        poly[3][3] = A[3] + 1.0;
+        poly[2][3] = B[3] + 1.0;
+    }
+
+    int n = clip_polygon(fc.planes, poly, 4);
+    if (n < 3) return;
+
+    QuadRec q;
+    double sz[MAX_POLY];
+    for (int i = 0; i < n; ++i) {
+        double c4[4], nd[4];
+        for (int j = 0; j < 4; ++j) c4[j] = row_times_col(poly[i], fc.mvp, j);
+        for (int j = 0; j < 4; ++j) nd[j] = c4[j] / c4[3];
+        q.sx[i] = row_times_col(nd, fc.viewport, 0);
+        q.sy[i] = row_times_col(nd, fc.viewport, 1);
+        sz[i] = row_times_col(nd, fc.viewport, 2);
+    }
+    for (int i = 0; i < n; ++i) {
+        int k1 = (i + 1 == n) ? 0 : i + 1;
+        q.ex[i] = q.sx[k1] - q.sx[i];
+        q.ey[i] = q.sy[k1] - q.sy[i];
+    }
+    for (int i = n; i < MAX_POLY; ++i) { q.sx[i] = q.sy[i] = q.ex[i] = q.ey[i] = 0; }
+    double ab[3] = { q.sx[0] - q.sx[1], q.sy[0] - q.sy[1], sz[0] - sz[1] };
+    double ac[3] = { q.sx[0] - q.sx[2], q.sy[0] - q.sy[2], sz[0] - sz[2] };
+    q.nx = ab[1] * ac[2] - ab[2] * ac[1];
+    q.ny = ab[2] * ac[0] - ab[0] * ac[2];
+    q.nz = ab[0] * ac[1] - ab[1] * ac[0];
+    q.is_front = q.nz < 0;
+    q.d = chain3(-q.sx[0], -q.sy[0], -sz[0], q.nx, q.ny, q.nz);
+    q.n = n;
+    q.edge = e;
+    q.pad = 0;
+    if (!bound_box(q.sx, q.sy, n, fc.width, fc.height, q.x0, q.x1, q.y0, q.y1)) return;
+    uint32_t slot = atomicAdd(&ctr->n_quads_drawn, 1u);
+    if (slot >= quad_cap) { atomicOr(&ctr->overflow, 4u); return; }
+    quads[slot] = q;
+}
+
+}  // namespace mr

@@ -1,0 +1,274 @@
+// kernels_shade.h -- deferred shading and finalise, one thread per pixel.
+//
+// The reference shades every z-passing fragment twice (ambient pass, then lit pass where
+// stencil == 0; obj/triangular.py:135-171) and converts the float frame at the end
+// (obj/core.py:640).  Because pass 2 re-tests against the final z buffer, the pixel's colour is
+// a function of (winner face, stencil == 0) only, so it is computed once here:
+//   stencil == 0 -> lit colour of the winner, else its ambient colour, no winner -> background;
+// then flipped, raised to 0.8, scaled to uint8.
+#pragma once
+
+#include "rast_math.h"
+
+namespace mr {
+
+struct ShadeArgs {
+    const TriRec *tris;
+    const int32_t *faces;
+    const uint8_t *face_flags;
+    const double *verts;
+    const float *uv;
+    const float *normals;
+    const Material *materials;
+    const Texture *textures;
+    const int32_t *winner;
+    const int16_t *stencil;
+    float *frame;          // optional float frame (row = screen y), may be null
+    uint8_t *out;          // band of the final frame, row 0 = top row of the band
+};
+
+// Face.get_UV (obj/core.py:138-143): nearest texel, truncation, Python negative-index wrap
+__device__ __forceinline__ const float *texel(const Texture &tx, const float *uv, const int ti[3],
+                                              const double p[3])
+{
+    const double tu = gemv3(p[0], p[1], p[2], (double)uv[ti[0] * 3], (double)uv[ti[1] * 3], (double)uv[ti[2] * 3]);
+    const double tv = gemv3(p[0], p[1], p[2], (double)uv[ti[0] * 3 + 1], (double)uv[ti[1] * 3 + 1],
+                            (double)uv[ti[2] * 3 + 1]);
+    const double cu = tu > 1.0 ? 1.0 : tu;
+    double rv = 1.0 - tv;
+    rv = rv > 1.0 ? 1.0 : rv;
+    int col = (int)(cu * (double)(tx.w - 1));
+    int row = (int)(rv * (double)(tx.h - 1));
+    if (col < 0) col += tx.w;
+    if (row < 0) row += tx.h;
+    col = min(max(col, 0), tx.w - 1);
+    row = min(max(row, 0), tx.h - 1);
+    return tx.rgb + ((size_t)row * tx.w + col) * 3;
+}
+
+// 3x3 inverse by LU with partial pivoting (np.linalg.inv -> LAPACK gesv)
+__device__ bool inv3(const double a[3][3], double inv[3][3])
+{
+    double lu[3][3];
+    int perm[3] = { 0, 1, 2 };
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lu[i][j] = a[i][j];
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+        int piv = col;
+        double best = fabs(lu[col][col]);
+        for (int r = col + 1; r < 3; ++r)
+            if (fabs(lu[r][col]) > best) { best = fabs(lu[r][col]); piv = r; }
+        if (best == 0) return false;
+        if (piv != col) {
+            for (int j = 0; j < 3; ++j) { double t = lu[col][j]; lu[col][j] = lu[piv][j]; lu[piv][j] = t; }
+            int t = perm[col]; perm[col] = perm[piv]; perm[piv] = t;
+        }
+        const double r = 1.0 / lu[col][col];
+        for (int i = col + 1; i < 3; ++i) {
+            lu[i][col] *= r;
+            for (int j = col + 1; j < 3; ++j) lu[i][j] = fma(-lu[i][col], lu[col][j], lu[i][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double y[3];
+        for (int i = 0; i < 3; ++i) {
+            double s = (perm[i] == j) ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s = fma(-lu[i][k], y[k], s);
+            y[i] = s;
+        }
+        for (int i = 2; i >= 0; --i) {
+            double s = y[i];
+            for (int k = i + 1; k < 3; ++k) s = fma(-lu[i][k], inv[k][j], s);
+            inv[i][j] = s / lu[i][i];
+        }
+    }
+    return true;
+}
+
+// ndarray ** scalar: NumPy's scalar-exponent fast paths, else pow()
+__device__ __forceinline__ double np_power(double x, double e)
+{
+    if (e == 2.0) return x * x;
+    if (e == 1.0) return x;
+    if (e == 0.5) return sqrt(x);
+    if (e == 0.0) return 1.0;
+    if (e == -1.0) return 1.0 / x;
+    return pow(x, e);
+}
+
+__device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v); }
+
+__global__ void __launch_bounds__(256)
+k_shade(const FrameConst fc, const ShadeArgs a)
+{
+    const int W = fc.width;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)W * (fc.band_y1 - fc.band_y0);
+    if (idx >= total) return;
+    const int px = (int)(idx % W);
+    const int py = fc.band_y0 + (int)(idx / W);
+    const size_t at = (size_t)py * W + px;
+
+    float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
+    const int f = a.winner[at];
+    if (f >= 0) {
+        const bool lit = a.stencil[at] == 0;
+        const TriRec t = a.tris[f];
+        const int32_t *fcx = a.faces + (size_t)f * 12;
+        const int vi[3] = { fcx[0], fcx[4], fcx[8] };
+        const int ti[3] = { fcx[1], fcx[5], fcx[9] };
+        const int ni[3] = { fcx[2], fcx[6], fcx[10] };
+        const Material &mat = a.materials[fcx[3]];
+        const uint8_t ff = a.face_flags[f];
+
+        float u, v, w;
+        tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
+        double p[3];
+        persp_bary(t, u, v, w, false, p);
+
+        double color[3];
+        if (mat.tex_kd >= 0) {
+            const float *tx = texel(a.textures[mat.tex_kd], a.uv, ti, p);
+            color[0] = tx[0]; color[1] = tx[1]; color[2] = tx[2];
+        } else {
+            color[0] = mat.kd[0]; color[1] = mat.kd[1]; color[2] = mat.kd[2];
+        }
+        const double *wa = a.verts + (size_t)vi[0] * 4, *wb = a.verts + (size_t)vi[1] * 4,
+                     *wc = a.verts + (size_t)vi[2] * 4;
+        double pos[3], dl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pos[j] = chain3(p[0], p[1], p[2], wa[j], wb[j], wc[j]);
+            dl[j] = fc.light_pos[j] - pos[j];
+        }
+        // Light.attenuation (obj/core.py:517-524)
+        const double dist = sqrt((dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2]);
+        const double att = 1.0 / (fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
+
+        if (!lit) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rgb[j] = (float)clip01((att * fc.light_ambient[j]) * color[j]);
+        } else {
+            // ---- Face.get_normals / tangent_ (obj/core.py:175-224)
+            double raw[3], interp[3] = { 0, 0, 0 };
+            const bool has_n = (ff & FF_HAS_NORMALS) != 0;
+            if (has_n) {
+                const float *n0 = a.normals + (size_t)ni[0] * 3, *n1 = a.normals + (size_t)ni[1] * 3,
+                            *n2 = a.normals + (size_t)ni[2] * 3;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    interp[j] = chain3(p[0], p[1], p[2], (double)n0[j], (double)n1[j], (double)n2[j]);
+            }
+            if (mat.tex_norm >= 0) {
+                const float *tx = texel(a.textures[mat.tex_norm], a.uv, ti, p);
+                if (mat.norm_tangent) {
+                    double n[3], A[3][3], AI[3][3];
+                    normalize3(interp, n);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (ff & FF_VERTS_F32) {
+                            A[0][j] = (double)((float)wb[j] - (float)wa[j]);
+                            A[1][j] = (double)((float)wc[j] - (float)wa[j]);
+                        } else {
+                            A[0][j] = wb[j] - wa[j];
+                            A[1][j] = wc[j] - wa[j];
+                        }
+                        A[2][j] = n[j];
+                    }
+                    if (!inv3(A, AI))
+                        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) AI[i][j] = NAN;
+                    const float u0 = a.uv[ti[0] * 3], u1 = a.uv[ti[1] * 3], u2 = a.uv[ti[2] * 3];
+                    const float w0 = a.uv[ti[0] * 3 + 1], w1 = a.uv[ti[1] * 3 + 1], w2 = a.uv[ti[2] * 3 + 1];
+                    const double du[2] = { (double)(u1 - u0), (double)(u2 - u0) };
+                    const double dv[2] = { (double)(w1 - w0), (double)(w2 - w0) };
+                    double ti_[3], tj_[3], T[3], Bt[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        ti_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], du[0], du[1], 0.0);
+                        tj_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], dv[0], dv[1], 0.0);
+                    }
+                    normalize3(ti_, T);
+                    normalize3(tj_, Bt);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        raw[r] = chain3(T[r], Bt[r], n[r], (double)tx[0], (double)tx[1], (double)tx[2]);
+                } else {
+                    raw[0] = tx[0]; raw[1] = tx[1]; raw[2] = tx[2];
+                }
+            } else if (has_n) {
+                raw[0] = interp[0]; raw[1] = interp[1]; raw[2] = interp[2];
+            } else {
+                // face normal (obj/core.py:127-130, 187), in the vertices' dtype
+                double fn[3];
+                if (ff & FF_VERTS_F32) {
+                    float e0[3], e1[3];
+                    for (int j = 0; j < 3; ++j) { e0[j] = (float)wb[j] - (float)wa[j]; e1[j] = (float)wc[j] - (float)wa[j]; }
+                    float cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                                    e0[0] * e1[1] - e0[1] * e1[0] };
+                    float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+                    if (l == 0) l = 1;
+                    for (int j = 0; j < 3; ++j) fn[j] = (double)(cr[j] / l);
+                } else {
+                    double e0[3], e1[3];
+                    for (int j = 0; j < 3; ++j) { e0[j] = wb[j] - wa[j]; e1[j] = wc[j] - wa[j]; }
+                    double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                                     e0[0] * e1[1] - e0[1] * e1[0] };
+                    normalize3(cr, fn);
+                }
+                for (int j = 0; j < 3; ++j) raw[j] = chain3(p[0], p[1], p[2], fn[j], fn[j], fn[j]);
+            }
+            double N[3], L[3], V[3], Hh[3], tmp[3];
+            normalize3(raw, N);
+
+            // ---- Blinn-Phong (obj/triangular.py:151-171)
+            if (fc.light_type == MR_LIGHT_DIRECTIONAL) {
+                L[0] = fc.light_dir[0]; L[1] = fc.light_dir[1]; L[2] = fc.light_dir[2];
+            } else {
+                normalize3(dl, L);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tmp[j] = fc.camera_pos[j] - pos[j];
+            normalize3(tmp, V);
+            if (fc.light_type == MR_LIGHT_SPOT) {
+                double x = (sum3(fc.light_dir, L) - fc.spot_edge0) / (fc.spot_edge1 - fc.spot_edge0);
+                x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+                const double in_light = x * x * (3 - 2 * x);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) color[j] = color[j] * in_light;
+            }
+            double spec_light[3];
+            if (mat.tex_ks >= 0) {
+                const float *tx = texel(a.textures[mat.tex_ks], a.uv, ti, p);
+                const float s = tx[0] * 255.0f;               // float32 product (obj/core.py:149)
+                spec_light[0] = spec_light[1] = spec_light[2] = (double)s;
+            } else {
+                spec_light[0] = mat.ks255[0]; spec_light[1] = mat.ks255[1]; spec_light[2] = mat.ks255[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tmp[j] = L[j] + V[j];
+            normalize3(tmp, Hh);
+            double nh = sum3(N, Hh);
+            nh = nh < 0 ? 0 : nh;
+            const double refl = np_power(nh, mat.ns);
+            const double nl = sum3(N, L);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double spec = ((fc.light_color[j] * refl) * fc.specular_strength) * spec_light[j];
+                const double diff = nl * fc.light_color[j];
+                rgb[j] = (float)clip01((att * color[j]) * ((fc.light_ambient[j] + diff) + spec));
+            }
+        }
+    }
+
+    if (a.frame) {
+        a.frame[at * 3 + 0] = rgb[0]; a.frame[at * 3 + 1] = rgb[1]; a.frame[at * 3 + 2] = rgb[2];
+    }
+    // finalise (obj/core.py:640): flip rows, ** 0.8, * 255, truncate
+    const int out_row = fc.band_y1 - 1 - py;
+    uint8_t *o = a.out + ((size_t)out_row * W + px) * 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = (uint8_t)(powf(rgb[j], 0.8f) * 255.0f);
+}
+
+}  // namespace mr

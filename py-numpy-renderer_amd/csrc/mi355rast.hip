@@ -1,0 +1,619 @@
+// mi355rast.hip -- C ABI (include/mi355rast.h) and host-side frame orchestration.
+//
+// One process drives one GPU.  A scene keeps its static arrays (vertices, attributes, index
+// arrays, textures, the unique-edge table for silhouettes) resident in HBM; a frame is a fixed
+// sequence of kernels on one HIP stream:
+//
+//   k_vertex -> k_tri_setup -> k_tri_count -> [k_silhouette] -> bin(count, scan, fill) x {tris, quads}
+//            -> k_tile_raster -> k_shade -> (D2H of the uint8 band)
+//
+// Built for gfx950 only, with -ffp-contract=off (see rast_math.h).
+#include "../../include/mi355rast.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rast_types.h"
+#include "kernels_geometry.h"
+#include "kernels_raster.h"
+#include "kernels_shade.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(MR_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+hipStream_t g_stream = nullptr;
+bool g_initialised = false;
+
+// growable device allocation
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct ModelInfo {
+    int32_t vert_off, n_verts, uv_off, n_uv, normal_off, n_normals, face_off, n_faces, mat_off, n_mats;
+};
+
+struct EdgeKey {
+    uint64_t key;      // (lo << 32) | hi of the two global vertex indices
+    uint32_t inc;      // face * 4 + corner
+};
+
+}  // namespace
+
+struct mr_scene {
+    // ---- host staging of the static scene (concatenated over models, indices made global)
+    std::vector<double> verts;
+    std::vector<float> uv, normals;
+    std::vector<int32_t> faces;
+    std::vector<uint8_t> face_flags;
+    std::vector<mr::Material> materials;
+    std::vector<mr::Texture> textures;       // device pointers
+    std::vector<void *> texture_allocs;
+    std::vector<ModelInfo> models;
+    std::vector<uint32_t> edge_offset, edge_inc;
+    bool dirty = true;
+
+    // ---- device copies of the static scene
+    DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
+    // ---- per-frame work buffers
+    DevBuf d_vout, d_tris, d_clips, d_status, d_lit, d_valid, d_quads, d_sil, d_counters;
+    DevBuf d_tri_count, d_tri_offset, d_tri_items, d_quad_count, d_quad_offset, d_quad_items;
+    DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
+    uint32_t tri_item_cap = 0, quad_item_cap = 0, quad_cap = 0;
+
+    mr::Counters *h_counters = nullptr;      // pinned
+    hipEvent_t ev[7] = {};
+    bool events_ok = false;
+
+    mr_frame_desc last_frame = {};
+    bool have_frame = false;
+    mr_stats stats = {};
+    int n_silhouette = 0;
+};
+
+namespace {
+
+int ensure_init()
+{
+    if (g_initialised) return MR_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MR_E_DEVICE, "no HIP device visible: libmi355rast has no CPU fallback");
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_initialised = true;
+    return MR_OK;
+}
+
+template <class T>
+int upload(DevBuf &buf, const std::vector<T> &v, hipStream_t s)
+{
+    HIP_TRY(buf.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return MR_OK;
+}
+
+// Unique undirected edges with their incident (face, corner) pairs in face order: what the
+// reference's per-model set of Edge objects (obj/triangular.py:286-302) reduces to.
+void build_edge_table(mr_scene *sc)
+{
+    const size_t nf = sc->faces.size() / 12;
+    std::vector<EdgeKey> keys;
+    keys.reserve(nf * 3);
+    for (size_t f = 0; f < nf; ++f) {
+        const int32_t *fc = &sc->faces[f * 12];
+        for (int k = 0; k < 3; ++k) {
+            uint32_t a = (uint32_t)fc[k * 4], b = (uint32_t)fc[((k + 1) % 3) * 4];
+            uint32_t lo = std::min(a, b), hi = std::max(a, b);
+            keys.push_back({ ((uint64_t)lo << 32) | hi, (uint32_t)(f * 4 + k) });
+        }
+    }
+    std::sort(keys.begin(), keys.end(), [](const EdgeKey &x, const EdgeKey &y) {
+        return x.key != y.key ? x.key < y.key : x.inc < y.inc;
+    });
+    sc->edge_offset.clear();
+    sc->edge_inc.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        if (i == 0 || keys[i].key != keys[i - 1].key) sc->edge_offset.push_back((uint32_t)i);
+        sc->edge_inc[i] = keys[i].inc;
+    }
+    sc->edge_offset.push_back((uint32_t)keys.size());
+}
+
+int commit(mr_scene *sc)
+{
+    if (!sc->dirty) return MR_OK;
+    build_edge_table(sc);
+    int rc;
+    if ((rc = upload(sc->d_verts, sc->verts, g_stream))) return rc;
+    if ((rc = upload(sc->d_uv, sc->uv, g_stream))) return rc;
+    if ((rc = upload(sc->d_normals, sc->normals, g_stream))) return rc;
+    if ((rc = upload(sc->d_faces, sc->faces, g_stream))) return rc;
+    if ((rc = upload(sc->d_face_flags, sc->face_flags, g_stream))) return rc;
+    if ((rc = upload(sc->d_materials, sc->materials, g_stream))) return rc;
+    if ((rc = upload(sc->d_textures, sc->textures, g_stream))) return rc;
+    if ((rc = upload(sc->d_edge_offset, sc->edge_offset, g_stream))) return rc;
+    if ((rc = upload(sc->d_edge_inc, sc->edge_inc, g_stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    sc->dirty = false;
+    return MR_OK;
+}
+
+int validate_frame(const mr_frame_desc *fr)
+{
+    if (!fr) return fail(MR_E_INVALID, "frame descriptor is NULL");
+    if (fr->width <= 0 || fr->height <= 0 || fr->width > 32768 || fr->height > 32768)
+        return fail(MR_E_INVALID, "resolution out of range");
+    if (fr->system != 1 && fr->system != -1) return fail(MR_E_INVALID, "system must be +1 (RH) or -1 (LH)");
+    if (fr->row_begin < 0 || fr->row_end > fr->height || fr->row_begin >= fr->row_end)
+        return fail(MR_E_INVALID, "row band must satisfy 0 <= row_begin < row_end <= height");
+    if (fr->light_type < 0 || fr->light_type > 2) return fail(MR_E_INVALID, "unknown light type");
+    return MR_OK;
+}
+
+mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
+{
+    mr::FrameConst fc;
+    std::memset(&fc, 0, sizeof fc);
+    fc.width = fr->width; fc.height = fr->height; fc.system = fr->system;
+    fc.backface_culling = fr->backface_culling; fc.light_type = fr->light_type; fc.flags = fr->flags;
+    // output rows count from the top, the reference's buffers from the bottom (obj/core.py:640 flips)
+    fc.band_y0 = fr->height - fr->row_end;
+    fc.band_y1 = fr->height - fr->row_begin;
+    fc.tile_y0 = fc.band_y0 / mr::TILE_H;
+    fc.tiles_x = (fr->width + mr::TILE_W - 1) / mr::TILE_W;
+    fc.tiles_y = (fc.band_y1 - 1) / mr::TILE_H + 1 - fc.tile_y0;
+    fc.n_vertices = (int32_t)(sc->verts.size() / 4);
+    fc.n_faces = (int32_t)(sc->faces.size() / 12);
+    fc.n_edges = sc->edge_offset.empty() ? 0 : (int32_t)sc->edge_offset.size() - 1;
+    std::memcpy(fc.mvp, fr->mvp, sizeof fc.mvp);
+    std::memcpy(fc.viewport, fr->viewport, sizeof fc.viewport);
+    std::memcpy(fc.debug_mvp, fr->debug_mvp, sizeof fc.debug_mvp);
+    std::memcpy(fc.planes, fr->frustum_planes, sizeof fc.planes);
+    fc.two_nf = 2 * fr->z_near * fr->z_far;          // obj/core.py:228, evaluated left to right
+    fc.f_plus_n = fr->z_far + fr->z_near;
+    fc.f_minus_n = fr->z_far - fr->z_near;
+    for (int j = 0; j < 3; ++j) {
+        fc.camera_pos[j] = fr->camera_pos[j];
+        fc.light_pos[j] = fr->light_pos[j]; fc.light_dir[j] = fr->light_dir[j];
+        fc.light_color[j] = fr->light_color[j]; fc.light_ambient[j] = fr->light_ambient[j];
+        fc.background[j] = fr->background[j];
+    }
+    fc.specular_strength = fr->specular_strength;
+    fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
+    fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;
+    return fc;
+}
+
+inline unsigned blocks_for(long long n, int per_block) { return (unsigned)std::max<long long>(1, (n + per_block - 1) / per_block); }
+
+// Enqueues one frame on `stream`.  d_out receives the uint8 band.
+int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStream_t stream)
+{
+    using namespace mr;
+    int rc = commit(sc);
+    if (rc) return rc;
+    const FrameConst fc = make_const(sc, fr);
+    const size_t npx = (size_t)fc.width * fc.height;
+    const int n_tiles = fc.tiles_x * fc.tiles_y;
+    const bool shadows = (fc.flags & MR_FRAME_SHADOWS) != 0;
+    const size_t nF = (size_t)std::max(fc.n_faces, 1), nV = (size_t)std::max(fc.n_vertices, 1);
+
+    if (sc->quad_cap == 0) sc->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
+    if (sc->tri_item_cap == 0) sc->tri_item_cap = (uint32_t)std::max<size_t>(4 * nF + 4 * (size_t)n_tiles, 1u << 20);
+    if (sc->quad_item_cap == 0) sc->quad_item_cap = 1u << 22;
+
+    HIP_TRY(sc->d_vout.ensure(nV * sizeof(VertexOut)));
+    HIP_TRY(sc->d_tris.ensure(nF * sizeof(TriRec)));
+    HIP_TRY(sc->d_clips.ensure(nF * sizeof(TriClip)));
+    HIP_TRY(sc->d_status.ensure(nF));
+    HIP_TRY(sc->d_lit.ensure(nF));
+    HIP_TRY(sc->d_valid.ensure(nF * sizeof(uint32_t)));
+    HIP_TRY(sc->d_quads.ensure((size_t)sc->quad_cap * sizeof(QuadRec)));
+    HIP_TRY(sc->d_sil.ensure((size_t)sc->quad_cap * 3 * sizeof(int32_t)));
+    HIP_TRY(sc->d_counters.ensure(sizeof(Counters)));
+    HIP_TRY(sc->d_tri_count.ensure((size_t)(n_tiles + 1) * 4));
+    HIP_TRY(sc->d_tri_offset.ensure((size_t)(n_tiles + 1) * 4));
+    HIP_TRY(sc->d_quad_count.ensure((size_t)(n_tiles + 1) * 4));
+    HIP_TRY(sc->d_quad_offset.ensure((size_t)(n_tiles + 1) * 4));
+    HIP_TRY(sc->d_tri_items.ensure((size_t)sc->tri_item_cap * 4));
+    HIP_TRY(sc->d_quad_items.ensure((size_t)sc->quad_item_cap * 4));
+    HIP_TRY(sc->d_z.ensure(npx * sizeof(double)));
+    HIP_TRY(sc->d_winner.ensure(npx * sizeof(int32_t)));
+    HIP_TRY(sc->d_stencil.ensure(npx * sizeof(int16_t)));
+    if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(sc->d_frame.ensure(npx * 3 * sizeof(float)));
+    if (!sc->events_ok) {
+        for (auto &e : sc->ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipHostMalloc((void **)&sc->h_counters, sizeof(Counters), hipHostMallocDefault));
+        sc->events_ok = true;
+    }
+
+    Counters *ctr = sc->d_counters.as<Counters>();
+    HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_tri_count.p, 0, (size_t)(n_tiles + 1) * 4, stream));
+    HIP_TRY(hipMemsetAsync(sc->d_quad_count.p, 0, (size_t)(n_tiles + 1) * 4, stream));
+    HIP_TRY(hipMemsetAsync(sc->d_quad_offset.p, 0, (size_t)(n_tiles + 1) * 4, stream));
+
+    // ---- geometry
+    if (fc.n_vertices > 0)
+        hipLaunchKernelGGL(k_vertex, dim3(blocks_for(fc.n_vertices, 256)), dim3(256), 0, stream, fc,
+                           sc->d_verts.as<double>(), sc->d_vout.as<VertexOut>());
+    if (fc.n_faces > 0) {
+        hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
+                           sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
+                           sc->d_vout.as<VertexOut>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
+                           sc->d_status.as<uint8_t>(), sc->d_lit.as<uint8_t>(), sc->d_valid.as<uint32_t>(), ctr);
+        hipLaunchKernelGGL(k_tri_count, dim3(blocks_for((long long)fc.n_faces * WAVE, 256)), dim3(256), 0, stream,
+                           fc, sc->d_valid.as<uint32_t>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
+                           sc->d_status.as<uint8_t>(), ctr);
+    }
+    if (shadows && fc.n_edges > 0)
+        hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 128)), dim3(128), 0, stream, fc,
+                           sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
+                           sc->d_lit.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
+                           sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
+    HIP_TRY(hipEventRecord(sc->ev[1], stream));
+
+    // ---- binning: count, scan, fill
+    const unsigned tri_blocks = blocks_for(fc.n_faces, 256);
+    const unsigned quad_blocks = blocks_for(std::min<long long>(fc.n_edges, sc->quad_cap), 256);
+    if (fc.n_faces > 0)
+        hipLaunchKernelGGL((k_bin<false, false>), dim3(tri_blocks), dim3(256), 0, stream, fc, sc->d_tris.as<TriRec>(),
+                           sc->d_valid.as<uint32_t>(), sc->d_status.as<uint8_t>(), (const QuadRec *)nullptr,
+                           (const Counters *)ctr, sc->quad_cap, sc->d_tri_count.as<uint32_t>(),
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_tri_count.as<uint32_t>(),
+                       sc->d_tri_offset.as<uint32_t>(), n_tiles, sc->tri_item_cap, &ctr->tri_bin_total, 1u, ctr);
+    if (fc.n_faces > 0)
+        hipLaunchKernelGGL((k_bin<true, false>), dim3(tri_blocks), dim3(256), 0, stream, fc, sc->d_tris.as<TriRec>(),
+                           sc->d_valid.as<uint32_t>(), sc->d_status.as<uint8_t>(), (const QuadRec *)nullptr,
+                           (const Counters *)ctr, sc->quad_cap, sc->d_tri_count.as<uint32_t>(),
+                           sc->d_tri_offset.as<uint32_t>(), sc->d_tri_items.as<uint32_t>(), sc->tri_item_cap);
+    if (shadows && fc.n_edges > 0) {
+        hipLaunchKernelGGL((k_bin<false, true>), dim3(quad_blocks), dim3(256), 0, stream, fc, (const TriRec *)nullptr,
+                           (const uint32_t *)nullptr, (const uint8_t *)nullptr, sc->d_quads.as<QuadRec>(),
+                           (const Counters *)ctr, sc->quad_cap, sc->d_quad_count.as<uint32_t>(),
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+        hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_quad_count.as<uint32_t>(),
+                           sc->d_quad_offset.as<uint32_t>(), n_tiles, sc->quad_item_cap, &ctr->quad_bin_total, 2u, ctr);
+        hipLaunchKernelGGL((k_bin<true, true>), dim3(quad_blocks), dim3(256), 0, stream, fc, (const TriRec *)nullptr,
+                           (const uint32_t *)nullptr, (const uint8_t *)nullptr, sc->d_quads.as<QuadRec>(),
+                           (const Counters *)ctr, sc->quad_cap, sc->d_quad_count.as<uint32_t>(),
+                           sc->d_quad_offset.as<uint32_t>(), sc->d_quad_items.as<uint32_t>(), sc->quad_item_cap);
+    }
+    HIP_TRY(hipEventRecord(sc->ev[2], stream));
+
+    // ---- visibility: coverage, z, stencil
+    hipLaunchKernelGGL(k_tile_raster, dim3(blocks_for(n_tiles, 256 / WAVE)), dim3(256), 0, stream, fc,
+                       sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(), sc->d_tri_offset.as<uint32_t>(),
+                       sc->d_tri_items.as<uint32_t>(), sc->tri_item_cap, sc->d_quads.as<QuadRec>(),
+                       sc->d_quad_offset.as<uint32_t>(), sc->d_quad_items.as<uint32_t>(), sc->quad_item_cap,
+                       sc->d_z.as<double>(), sc->d_winner.as<int32_t>(), sc->d_stencil.as<int16_t>(), ctr);
+    HIP_TRY(hipEventRecord(sc->ev[3], stream));
+
+    // ---- deferred shading + finalise
+    ShadeArgs sa;
+    sa.tris = sc->d_tris.as<TriRec>(); sa.faces = sc->d_faces.as<int32_t>();
+    sa.face_flags = sc->d_face_flags.as<uint8_t>(); sa.verts = sc->d_verts.as<double>();
+    sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
+    sa.materials = sc->d_materials.as<Material>(); sa.textures = sc->d_textures.as<Texture>();
+    sa.winner = sc->d_winner.as<int32_t>(); sa.stencil = sc->d_stencil.as<int16_t>();
+    sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? sc->d_frame.as<float>() : nullptr;
+    sa.out = d_out;
+    const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(band_px, 256)), dim3(256), 0, stream, fc, sa);
+    HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    HIP_TRY(hipMemcpyAsync(sc->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipGetLastError());
+    sc->last_frame = *fr;
+    sc->have_frame = true;
+    return MR_OK;
+}
+
+// After the stream has drained: turn counters + events into mr_stats; grow work lists on overflow.
+int collect(mr_scene *sc, bool with_copy)
+{
+    const mr::Counters &c = *sc->h_counters;
+    mr_stats &s = sc->stats;
+    s.frag_tri = (int64_t)c.frag_tri; s.frag_quad = (int64_t)c.frag_quad;
+    s.covered_px = (int64_t)c.covered_px; s.lit_px = (int64_t)c.lit_px;
+    s.stencil_updates = (int64_t)c.stencil_updates;
+    s.n_faces = (int64_t)(sc->faces.size() / 12); s.n_faces_setup = c.n_valid_tris;
+    s.n_quads = c.n_quads; s.n_quads_drawn = c.n_quads_drawn;
+    s.tri_bin_entries = c.tri_bin_total; s.quad_bin_entries = c.quad_bin_total;
+    sc->n_silhouette = (int)c.n_quads;
+    float ms = 0;
+    auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, sc->ev[a], sc->ev[b]); return ms; };
+    s.gpu_ms_geometry = span(0, 1); s.gpu_ms_binning = span(1, 2); s.gpu_ms_raster = span(2, 3);
+    s.gpu_ms_shade = span(3, 4);
+    s.gpu_ms_copy = with_copy ? span(4, 5) : 0.f;
+    s.gpu_ms_total = span(0, with_copy ? 5 : 4);
+    if (c.overflow) {
+        if (c.overflow & 1u) { sc->tri_item_cap = c.tri_bin_total + c.tri_bin_total / 2 + 1024; }
+        if (c.overflow & 2u) { sc->quad_item_cap = c.quad_bin_total + c.quad_bin_total / 2 + 1024; }
+        if (c.overflow & 4u) { sc->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, sc->quad_cap * 2); }
+        if (c.n_quads > sc->quad_cap) sc->quad_cap = c.n_quads + c.n_quads / 2 + 64;
+        return MR_E_OVERFLOW;
+    }
+    if (c.n_quads > sc->quad_cap) { sc->quad_cap = c.n_quads + c.n_quads / 2 + 64; return MR_E_OVERFLOW; }
+    return MR_OK;
+}
+
+template <class T>
+int read_back(mr_scene *sc, const DevBuf &buf, T *out, size_t count, const char *what)
+{
+    if (!sc || !out) return fail(MR_E_INVALID, "NULL argument");
+    if (!sc->have_frame || !buf.p) return fail(MR_E_INVALID, std::string(what) + ": nothing rendered yet");
+    HIP_TRY(hipMemcpy(out, buf.p, count * sizeof(T), hipMemcpyDeviceToHost));
+    return MR_OK;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+
+extern "C" {
+
+int mr_abi_version(void) { return MR_ABI_VERSION; }
+
+int mr_device_available(void)
+{
+    int n = 0;
+    return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0;
+}
+
+int mr_init(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MR_E_DEVICE, "no HIP device visible: libmi355rast has no CPU fallback");
+    if (device >= 0) {
+        if (device >= n) return fail(MR_E_INVALID, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+    }
+    return ensure_init();
+}
+
+const char *mr_last_error(void) { return g_error.c_str(); }
+
+mr_scene *mr_scene_create(void)
+{
+    mr_scene *sc = new (std::nothrow) mr_scene();
+    if (!sc) fail(MR_E_DEVICE, "out of host memory");
+    return sc;
+}
+
+int mr_scene_clear(mr_scene *sc)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    for (void *p : sc->texture_allocs) (void)hipFree(p);
+    sc->texture_allocs.clear(); sc->textures.clear();
+    sc->verts.clear(); sc->uv.clear(); sc->normals.clear(); sc->faces.clear(); sc->face_flags.clear();
+    sc->materials.clear(); sc->models.clear(); sc->edge_offset.clear(); sc->edge_inc.clear();
+    sc->dirty = true; sc->have_frame = false;
+    sc->tri_item_cap = sc->quad_item_cap = sc->quad_cap = 0;
+    return MR_OK;
+}
+
+void mr_scene_destroy(mr_scene *sc)
+{
+    if (!sc) return;
+    if (g_initialised) (void)hipStreamSynchronize(g_stream);
+    mr_scene_clear(sc);
+    DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
+                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_vout, &sc->d_tris, &sc->d_clips,
+                       &sc->d_status, &sc->d_lit, &sc->d_valid, &sc->d_quads, &sc->d_sil, &sc->d_counters,
+                       &sc->d_tri_count, &sc->d_tri_offset, &sc->d_tri_items, &sc->d_quad_count, &sc->d_quad_offset,
+                       &sc->d_quad_items, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
+    for (DevBuf *b : bufs) b->release();
+    if (sc->events_ok) {
+        for (auto &e : sc->ev) (void)hipEventDestroy(e);
+        (void)hipHostFree(sc->h_counters);
+    }
+    delete sc;
+}
+
+int mr_scene_add_texture(mr_scene *sc, const float *rgb, int32_t h, int32_t w)
+{
+    if (!sc || !rgb) return fail(MR_E_INVALID, "NULL argument");
+    if (h <= 0 || w <= 0) return fail(MR_E_INVALID, "texture size must be positive");
+    int rc = ensure_init();
+    if (rc) return rc;
+    void *d = nullptr;
+    const size_t bytes = (size_t)h * w * 3 * sizeof(float);
+    HIP_TRY(hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpy(d, rgb, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(MR_E_DEVICE, hipGetErrorString(e)); }
+    sc->texture_allocs.push_back(d);
+    sc->textures.push_back({ static_cast<const float *>(d), h, w });
+    sc->dirty = true;
+    return (int)sc->textures.size() - 1;
+}
+
+int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
+{
+    if (!sc || !m) return fail(MR_E_INVALID, "NULL argument");
+    if (!m->vertices || !m->faces || !m->materials || m->n_vertices <= 0 || m->n_faces < 0 || m->n_materials <= 0)
+        return fail(MR_E_INVALID, "model needs vertices, faces and at least one material");
+    if (!m->depth_test)
+        return fail(MR_E_UNSUPPORTED, "Model.depth_test=False makes the result depend on face order; not implemented");
+    const int n_tex = (int)sc->textures.size();
+    for (int i = 0; i < m->n_materials; ++i) {
+        const mr_material &mm = m->materials[i];
+        if (mm.tex_kd >= n_tex || mm.tex_norm >= n_tex || mm.tex_ks >= n_tex)
+            return fail(MR_E_INVALID, "material refers to a texture id that was never added");
+        if ((mm.tex_kd >= 0 || mm.tex_norm >= 0 || mm.tex_ks >= 0) && !m->uv)
+            return fail(MR_E_INVALID, "textured material on a model without uv coordinates");
+        if (mm.tex_norm >= 0 && mm.norm_tangent && !m->normals)
+            return fail(MR_E_INVALID, "tangent-space normal map on a model without vertex normals");
+    }
+    ModelInfo mi;
+    mi.vert_off = (int32_t)(sc->verts.size() / 4); mi.n_verts = m->n_vertices;
+    mi.uv_off = (int32_t)(sc->uv.size() / 3); mi.n_uv = m->uv ? m->n_uv : 0;
+    mi.normal_off = (int32_t)(sc->normals.size() / 3); mi.n_normals = m->normals ? m->n_normals : 0;
+    mi.face_off = (int32_t)(sc->faces.size() / 12); mi.n_faces = m->n_faces;
+    mi.mat_off = (int32_t)sc->materials.size(); mi.n_mats = m->n_materials;
+    // validate indices before touching the scene: the kernels trust them
+    for (int64_t i = 0; i < (int64_t)m->n_faces * 3; ++i) {
+        const int32_t *c = m->faces + i * 4;
+        if (c[0] < 0 || c[0] >= m->n_vertices) return fail(MR_E_INVALID, "vertex index out of range");
+        if (m->uv && (c[1] < 0 || c[1] >= m->n_uv)) return fail(MR_E_INVALID, "uv index out of range");
+        if (m->normals && (c[2] < 0 || c[2] >= m->n_normals)) return fail(MR_E_INVALID, "normal index out of range");
+        if (c[3] < 0 || c[3] >= m->n_materials) return fail(MR_E_INVALID, "material index out of range");
+    }
+    sc->verts.insert(sc->verts.end(), m->vertices, m->vertices + (size_t)m->n_vertices * 4);
+    if (m->uv) sc->uv.insert(sc->uv.end(), m->uv, m->uv + (size_t)m->n_uv * 3);
+    if (m->normals) sc->normals.insert(sc->normals.end(), m->normals, m->normals + (size_t)m->n_normals * 3);
+    for (int i = 0; i < m->n_materials; ++i) {
+        const mr_material &mm = m->materials[i];
+        mr::Material d;
+        for (int j = 0; j < 3; ++j) { d.kd[j] = mm.kd[j]; d.ks255[j] = mm.ks255[j]; }
+        d.ns = mm.ns; d.tex_kd = mm.tex_kd; d.tex_norm = mm.tex_norm; d.tex_ks = mm.tex_ks;
+        d.norm_tangent = mm.norm_tangent;
+        sc->materials.push_back(d);
+    }
+    const uint8_t ff = (uint8_t)((m->clip ? mr::FF_CLIP : 0) | (m->vertices_are_f32 ? mr::FF_VERTS_F32 : 0) |
+                                 (m->normals ? mr::FF_HAS_NORMALS : 0) | (m->uv ? mr::FF_HAS_UV : 0));
+    sc->faces.reserve(sc->faces.size() + (size_t)m->n_faces * 12);
+    for (int64_t i = 0; i < (int64_t)m->n_faces * 3; ++i) {
+        const int32_t *c = m->faces + i * 4;
+        sc->faces.push_back(c[0] + mi.vert_off);
+        sc->faces.push_back(m->uv ? c[1] + mi.uv_off : 0);
+        sc->faces.push_back(m->normals ? c[2] + mi.normal_off : 0);
+        sc->faces.push_back(c[3] + mi.mat_off);
+    }
+    sc->face_flags.insert(sc->face_flags.end(), (size_t)m->n_faces, ff);
+    sc->models.push_back(mi);
+    sc->dirty = true;
+    sc->tri_item_cap = sc->quad_item_cap = sc->quad_cap = 0;
+    return (int)sc->models.size() - 1;
+}
+
+int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats *stats)
+{
+    if (!sc || !out_rgb) return fail(MR_E_INVALID, "NULL argument");
+    int rc = validate_frame(fr);
+    if (rc) return rc;
+    if ((rc = ensure_init())) return rc;
+    const size_t band_bytes = (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        HIP_TRY(sc->d_out.ensure(band_bytes));
+        if ((rc = enqueue_frame(sc, fr, sc->d_out.as<uint8_t>(), g_stream))) return rc;
+        HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipEventRecord(sc->ev[5], g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        rc = collect(sc, true);
+        if (rc == MR_OK) {
+            if (stats) *stats = sc->stats;
+            return MR_OK;
+        }
+        if (rc != MR_E_OVERFLOW) return rc;       // work lists were grown: render the frame again
+    }
+    return fail(MR_E_OVERFLOW, "work lists kept overflowing");
+}
+
+int mr_render_device(mr_scene *sc, const mr_frame_desc *fr, void *d_out_rgb, void *stream)
+{
+    if (!sc || !d_out_rgb) return fail(MR_E_INVALID, "NULL argument");
+    int rc = validate_frame(fr);
+    if (rc) return rc;
+    if ((rc = ensure_init())) return rc;
+    return enqueue_frame(sc, fr, static_cast<uint8_t *>(d_out_rgb), stream ? (hipStream_t)stream : g_stream);
+}
+
+int mr_get_stats(mr_scene *sc, mr_stats *stats)
+{
+    if (!sc || !stats) return fail(MR_E_INVALID, "NULL argument");
+    if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = collect(sc, false);
+    *stats = sc->stats;
+    if (rc == MR_E_OVERFLOW)
+        return fail(MR_E_OVERFLOW, "the last frame overflowed a work list (now grown): render it again");
+    return rc;
+}
+
+int mr_read_z(mr_scene *sc, double *out)
+{
+    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    return read_back(sc, sc->d_z, out, (size_t)sc->last_frame.width * sc->last_frame.height, "z");
+}
+int mr_read_stencil(mr_scene *sc, int16_t *out)
+{
+    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    return read_back(sc, sc->d_stencil, out, (size_t)sc->last_frame.width * sc->last_frame.height, "stencil");
+}
+int mr_read_winner(mr_scene *sc, int32_t *out)
+{
+    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    return read_back(sc, sc->d_winner, out, (size_t)sc->last_frame.width * sc->last_frame.height, "winner");
+}
+int mr_read_frame_f32(mr_scene *sc, float *out)
+{
+    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    if (!(sc->last_frame.flags & MR_FRAME_KEEP_FLOAT))
+        return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_KEEP_FLOAT");
+    return read_back(sc, sc->d_frame, out, (size_t)sc->last_frame.width * sc->last_frame.height * 3, "frame");
+}
+int mr_read_face_status(mr_scene *sc, uint8_t *out)
+{
+    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    return fail(MR_E_UNSUPPORTED, "per-face status of the lit pass is not implemented yet");
+    (void)out;
+}
+
+int mr_read_silhouette(mr_scene *sc, int32_t *out, int32_t cap)
+{
+    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    const int n = sc->n_silhouette;
+    const int take = std::min(std::min(n, cap), (int)sc->quad_cap);
+    if (take > 0 && out) {
+        std::vector<int32_t> raw((size_t)take * 3);
+        HIP_TRY(hipMemcpy(raw.data(), sc->d_sil.p, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < take; ++i) {
+            const int face = raw[i * 3];
+            int model = 0;
+            while (model + 1 < (int)sc->models.size() && face >= sc->models[model + 1].face_off) ++model;
+            out[i * 3 + 0] = model;
+            out[i * 3 + 1] = raw[i * 3 + 1] - sc->models[model].vert_off;
+            out[i * 3 + 2] = raw[i * 3 + 2] - sc->models[model].vert_off;
+        }
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// rast_math.h -- device arithmetic in the exact operation order of the reference.
+//
+// The reference evaluates its products through NumPy/OpenBLAS, which fixes a rounding order
+// per call shape.  Coverage, clip decisions and z must be bit-exact,
+// so every such product is written out here as an explicit fma chain; element-wise NumPy
+// expressions stay separate rounded operations.  The translation unit is compiled with
+// -ffp-contract=off: nothing is fused unless it is spelled fma() below.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace mr {
+
+// 1-D dot and GEMM (M,K)@(K,P>=2): ascending k, first term a rounded product.
+__device__ __forceinline__ double chain2(double a0, double a1, double b0, double b1)
+{
+    return fma(a1, b1, a0 * b0);
+}
+__device__ __forceinline__ double chain3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return fma(a2, b2, fma(a1, b1, a0 * b0));
+}
+__device__ __forceinline__ double chain4(double a0, double a1, double a2, double a3,
+                                         double b0, double b1, double b2, double b3)
+{
+    return fma(a3, b3, fma(a2, b2, fma(a1, b1, a0 * b0)));
+}
+// row @ column j of a row-major 4x4
+__device__ __forceinline__ double row_times_col(const double v[4], const double *m, int j)
+{
+    return chain4(v[0], v[1], v[2], v[3], m[j], m[4 + j], m[8 + j], m[12 + j]);
+}
+// GEMV (N,2)@(2,), N > 1
+__device__ __forceinline__ double gemv2(double a0, double a1, double b0, double b1)
+{
+    return fma(a0, b0, a1 * b1);
+}
+// GEMV (N,3)@(3,), N > 1
+__device__ __forceinline__ double gemv3(double a0, double a1, double a2, double b0, double b1, double b2)
+{
+    return fma(a2, b2, fma(a0, b0, a1 * b1));
+}
+// (N,K)@(K,) as NumPy dispatches it: one row -> dot (ascending chain), else gemv
+__device__ __forceinline__ double rows_dot2(bool single, double a0, double a1, double b0, double b1)
+{
+    return single ? chain2(a0, a1, b0, b1) : gemv2(a0, a1, b0, b1);
+}
+__device__ __forceinline__ double rows_dot3(bool single, double a0, double a1, double a2,
+                                            double b0, double b1, double b2)
+{
+    return single ? chain3(a0, a1, a2, b0, b1, b2) : gemv3(a0, a1, a2, b0, b1, b2);
+}
+// (a*b).sum(axis=1), K = 3: no fusion, left to right
+__device__ __forceinline__ double sum3(const double a[3], const double b[3])
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+// normalize() of obj/transformation.py:46-49 for one float64 3-vector
+__device__ __forceinline__ void normalize3(const double a[3], double o[3])
+{
+    double l = sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+    if (l == 0) l = 1;
+    o[0] = a[0] / l; o[1] = a[1] / l; o[2] = a[2] / l;
+}
+
+__device__ __forceinline__ double linearize_z(const FrameConst &fc, double d)
+{
+    return fc.two_nf / (fc.f_plus_n - d * fc.f_minus_n);
+}
+
+// float32 barycentrics of an integer sample (obj/transformation.py:18-31).
+// dpx, dpy are the sample coordinates already widened to double.
+__device__ __forceinline__ void tri_bary(const TriRec &t, double dpx, double dpy, bool single,
+                                         float &u, float &v, float &w)
+{
+    double rx = dpx - t.ax, ry = dpy - t.ay;
+    float d20 = (float)rows_dot2(single, rx, ry, t.v0x, t.v0y);
+    float d21 = (float)rows_dot2(single, rx, ry, t.v1x, t.v1y);
+    v = (t.d11 * d20 - t.d01 * d21) * t.inv_den;
+    w = (t.d00 * d21 - t.d01 * d20) * t.inv_den;
+    u = 1.0f - v - w;
+}
+
+// Face.screen_perspective (obj/core.py:155-160)
+__device__ __forceinline__ void persp_bary(const TriRec &t, float u, float v, float w, bool single,
+                                           double p[3])
+{
+    double wc = rows_dot3(single, (double)u, (double)v, (double)w, t.dp0, t.dp1, t.dp2);
+    p[0] = ((double)u * t.dp0) / wc;
+    p[1] = ((double)v * t.dp1) / wc;
+    p[2] = ((double)w * t.dp2) / wc;
+}
+
+// strict -w < x,y,z < w in one camera's clip space (obj/triangular.py:83-87)
+__device__ __forceinline__ bool inside_clip(const double p[3], const double cs[3][4])
+{
+    double q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = chain3(p[0], p[1], p[2], cs[0][j], cs[1][j], cs[2][j]);
+    return (-q[3] < q[0]) && (q[0] < q[3]) && (-q[3] < q[1]) && (q[1] < q[3]) &&
+           (-q[3] < q[2]) && (q[2] < q[3]);
+}
+
+// transformation.py:35-43 bound_box for n points; false when empty.
+__device__ __forceinline__ bool bound_box(const double *xs, const double *ys, int n, int W, int H,
+                                          int &x0, int &x1, int &y0, int &y1)
+{
+    double lo_x = xs[0], hi_x = xs[0], lo_y = ys[0], hi_y = ys[0];
+    for (int i = 1; i < n; ++i) {
+        lo_x = xs[i] < lo_x ? xs[i] : lo_x;  hi_x = xs[i] > hi_x ? xs[i] : hi_x;
+        lo_y = ys[i] < lo_y ? ys[i] : lo_y;  hi_y = ys[i] > hi_y ? ys[i] : hi_y;
+    }
+    lo_x = lo_x < 0 ? 0 : lo_x;  hi_x = hi_x > W ? (double)W : hi_x;
+    lo_y = lo_y < 0 ? 0 : lo_y;  hi_y = hi_y > H ? (double)H : hi_y;
+    if (lo_x > hi_x || lo_y > hi_y) return false;
+    // the clamps keep the integer box inside the frame even for non-finite input
+    x0 = min(max((int)ceil(lo_x), 0), W);  x1 = min(max((int)ceil(hi_x), 0), W);
+    y0 = min(max((int)ceil(lo_y), 0), H);  y1 = min(max((int)ceil(hi_y), 0), H);
+    return true;
+}
+
+}  // namespace mr

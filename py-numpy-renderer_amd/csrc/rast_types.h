@@ -1,0 +1,117 @@
+// rast_types.h -- records shared by the host side of libmi355rast and its gfx950 kernels.
+//
+// Vocabulary follows the reference renderer: faces (triangles), silhouette edges, shadow
+// quads, fragments, z / stencil / frame buffers.  A "tile" is the block of TILE_W x TILE_H
+// pixels owned by one 64-lane wavefront in the visibility kernel.
+#pragma once
+
+#include <stdint.h>
+
+namespace mr {
+
+constexpr int TILE_W = 8;
+constexpr int TILE_H = 8;
+constexpr int WAVE = 64;
+static_assert(TILE_W * TILE_H == WAVE, "one pixel per lane");
+
+constexpr int MAX_POLY = 12;   // a quad clipped by six planes has at most 4 + 6 vertices
+
+// Status codes are the reference's Errors flag values (obj/triangular.py:15-20).
+enum : uint8_t {
+    FACE_OK = 0, FACE_BACK_FACE_CULLING = 1, FACE_WRONG_MIN_MAX = 2,
+    FACE_EMPTY_B = 4, FACE_EMPTY_Z = 8, FACE_CLIPPED = 16
+};
+
+// per-face flags copied from the owning Model
+enum : uint8_t { FF_CLIP = 1, FF_VERTS_F32 = 2, FF_HAS_NORMALS = 4, FF_HAS_UV = 8 };
+
+// TriRec.flags
+enum : uint32_t {
+    TF_CLIP = 1,          // Model.clip: per-fragment frustum test against both cameras
+    TF_SINGLE_BOX = 2,    // pixel box holds exactly one sample  -> NumPy's (1,K)@(K,) is a dot
+    TF_SINGLE_Z = 4       // exactly one fragment survives coverage + clip -> z is a dot
+};
+
+// Per-frame constants, passed to every kernel by value (kernarg segment, scalar loads).
+struct FrameConst {
+    int32_t width, height;
+    int32_t system;              // +1 RH, -1 LH
+    int32_t backface_culling;
+    int32_t light_type;
+    int32_t flags;
+    int32_t band_y0, band_y1;    // screen rows [band_y0, band_y1) this device owns (y up, unflipped)
+    int32_t tiles_x, tiles_y;    // tile grid of the band
+    int32_t tile_y0;             // first tile row of the band (in full-frame tile rows)
+    int32_t n_vertices, n_faces, n_edges;
+    double mvp[16], viewport[16], debug_mvp[16];
+    double planes[24];
+    double two_nf, f_plus_n, f_minus_n;      // linearize_z constants (obj/core.py:226-228)
+    double camera_pos[3];
+    double light_pos[3], light_dir[3], light_color[3], light_ambient[3];
+    double specular_strength, att_constant, att_linear, att_quadratic;
+    double spot_edge0, spot_edge1;
+    float background[3];
+    int32_t pad;
+};
+
+// Output of the vertex kernel: everything obj/triangular.py:36-45 derives per face corner,
+// computed once per unique vertex.
+struct VertexOut {
+    double sx, sy, sz, depth;    // screen x, y, z and 1/clip.w
+    double clip[4];              // v @ camera.MVP
+    double clipd[4];             // v @ debug_camera.MVP
+    double zlin;                 // linearize_z(sz)
+};
+
+// Triangle set-up record consumed by the visibility and shading kernels
+// (the per-face constants of obj/transformation.py:12-32 and obj/triangular.py:96-97).
+struct TriRec {
+    double ax, ay;               // screen position of corner a
+    double v0x, v0y, v1x, v1y;   // b - a, c - a
+    double zl0, zl1, zl2;        // linearised z of the corners
+    double dp0, dp1, dp2;        // 1/w of the corners
+    float d00, d01, d11, inv_den;
+    int32_t x0, x1, y0, y1;      // half-open pixel box
+    uint32_t flags;
+    int32_t face;                // global face index
+};
+
+struct TriClip {
+    double clip[3][4];
+    double clipd[3][4];
+};
+
+// Shadow quad after extrusion, clipping and projection (obj/triangular.py:319-349).
+struct QuadRec {
+    double sx[MAX_POLY], sy[MAX_POLY];   // screen vertices
+    double ex[MAX_POLY], ey[MAX_POLY];   // edge vectors p[i+1] - p[i]
+    double nx, ny, nz, d;                // plane through the first three vertices
+    int32_t n;                           // vertex count (>= 3)
+    int32_t is_front;
+    int32_t x0, x1, y0, y1;              // half-open pixel box
+    int32_t edge;                        // unique-edge index it came from
+    int32_t pad;
+};
+
+struct Material {
+    double kd[3];
+    double ks255[3];
+    double ns;
+    int32_t tex_kd, tex_norm, tex_ks, norm_tangent;
+};
+
+struct Texture {
+    const float *rgb;
+    int32_t h, w;
+};
+
+// Device-side counters of one frame; copied back once at the end.
+struct Counters {
+    unsigned long long frag_tri, frag_quad, covered_px, lit_px, stencil_updates;
+    unsigned int n_valid_tris, n_quads, n_quads_drawn;
+    unsigned int tri_bin_total, quad_bin_total;
+    unsigned int overflow;       // bit0: triangle bins, bit1: quad bins, bit2: quad list
+    unsigned int pad;
+};
+
+}  // namespace mr
