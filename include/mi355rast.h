@@ -156,6 +156,14 @@ int mr_render_device(mr_scene *scene, const mr_frame_desc *frame, void *d_out_rg
 /* Counters / timings of the last mr_render on this scene. */
 int mr_get_stats(mr_scene *scene, mr_stats *stats);
 
+/* Average device time in milliseconds (HIP events on the stream the kernels ran on) of each
+ * stage over the last n_frames frames, most recent first; at most 128 are remembered.
+ *   [0] k_vertex + k_tri_setup   [1] k_tri_count   [2] k_silhouette   [3] triangle binning (3 kernels)
+ *   [4] quad binning (3 kernels) [5] k_tile_raster [6] k_shade        [7] whole frame (start -> after k_shade)
+ * Synchronises the device.  Returns the number of frames averaged or a negative error. */
+#define MR_N_KERNEL_TIMES 8
+int mr_get_kernel_times(mr_scene *scene, int n_frames, float *out_ms, int cap);
+
 /* Debug taps for parity tests: the reference's working buffers after the last render
  * (obj/core.py:588-591).  Row = screen y (not flipped), as in the reference. */
 int mr_read_z(mr_scene *scene, double *out_hw);            /* z_buffer, float64 (H, W) */

@@ -72,6 +72,7 @@ _PROTOTYPES = {
     "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "mr_render_device": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p]),
     "mr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "mr_get_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "mr_read_z": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_stencil": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_winner": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -214,6 +215,15 @@ class DeviceRenderer:
         _check(self.lib.mr_get_stats(self.handle, C.byref(st)), "mr_get_stats")
         self.last_stats = st.as_dict()
         return self.last_stats
+
+    KERNEL_TIME_NAMES = ("vertex+tri_setup", "tri_count", "silhouette", "bin_tris", "bin_quads",
+                         "tile_raster", "shade", "frame")
+
+    def kernel_times(self, n_frames):
+        """Average per-stage device milliseconds over the last *n_frames* frames (syncs)."""
+        buf = (C.c_float * 8)()
+        n = _check(self.lib.mr_get_kernel_times(self.handle, int(n_frames), buf, 8), "mr_get_kernel_times")
+        return dict(zip(self.KERNEL_TIME_NAMES, (float(v) for v in buf))), n
 
     # -- debug taps -----------------------------------------------------------------------
     def _tap(self, fn, dtype, extra=()):

@@ -95,7 +95,14 @@ struct mr_scene {
     uint32_t tri_item_cap = 0, quad_item_cap = 0, quad_cap = 0;
 
     mr::Counters *h_counters = nullptr;      // pinned
-    hipEvent_t ev[7] = {};
+    // Event marks of the last EVENT_RING frames (frames are enqueued without host syncs, so a
+    // bench that times K frames can still average each kernel's duration over them afterwards).
+    // Marks: 0 start | 1 vertex+tri_setup | 2 tri_count | 3 silhouette | 4 triangle bins |
+    //        5 quad bins | 6 tile raster | 7 shade | 8 device->host copy
+    static constexpr int EVENT_RING = 128, N_MARKS = 9;
+    hipEvent_t ev_ring[EVENT_RING][N_MARKS] = {};
+    hipEvent_t *ev = ev_ring[0];
+    uint64_t frames_enqueued = 0;
     bool events_ok = false;
 
     mr_frame_desc last_frame = {};
@@ -256,10 +263,11 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     HIP_TRY(sc->d_stencil.ensure(npx * sizeof(int16_t)));
     if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(sc->d_frame.ensure(npx * 3 * sizeof(float)));
     if (!sc->events_ok) {
-        for (auto &e : sc->ev) HIP_TRY(hipEventCreate(&e));
+        for (auto &set : sc->ev_ring) for (auto &e : set) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipHostMalloc((void **)&sc->h_counters, sizeof(Counters), hipHostMallocDefault));
         sc->events_ok = true;
     }
+    sc->ev = sc->ev_ring[sc->frames_enqueued % mr_scene::EVENT_RING];
 
     Counters *ctr = sc->d_counters.as<Counters>();
     HIP_TRY(hipEventRecord(sc->ev[0], stream));
@@ -277,16 +285,20 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
                            sc->d_vout.as<VertexOut>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
                            sc->d_status.as<uint8_t>(), sc->d_lit.as<uint8_t>(), sc->d_valid.as<uint32_t>(), ctr);
+        HIP_TRY(hipEventRecord(sc->ev[1], stream));
         hipLaunchKernelGGL(k_tri_count, dim3(blocks_for((long long)fc.n_faces * WAVE, 256)), dim3(256), 0, stream,
                            fc, sc->d_valid.as<uint32_t>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
                            sc->d_status.as<uint8_t>(), ctr);
+    } else {
+        HIP_TRY(hipEventRecord(sc->ev[1], stream));
     }
+    HIP_TRY(hipEventRecord(sc->ev[2], stream));
     if (shadows && fc.n_edges > 0)
         hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 128)), dim3(128), 0, stream, fc,
                            sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
                            sc->d_lit.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
                            sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
-    HIP_TRY(hipEventRecord(sc->ev[1], stream));
+    HIP_TRY(hipEventRecord(sc->ev[3], stream));
 
     // ---- binning: count, scan, fill
     const unsigned tri_blocks = blocks_for(fc.n_faces, 256);
@@ -303,6 +315,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                            sc->d_valid.as<uint32_t>(), sc->d_status.as<uint8_t>(), (const QuadRec *)nullptr,
                            (const Counters *)ctr, sc->quad_cap, sc->d_tri_count.as<uint32_t>(),
                            sc->d_tri_offset.as<uint32_t>(), sc->d_tri_items.as<uint32_t>(), sc->tri_item_cap);
+    HIP_TRY(hipEventRecord(sc->ev[4], stream));
     if (shadows && fc.n_edges > 0) {
         hipLaunchKernelGGL((k_bin<false, true>), dim3(quad_blocks), dim3(256), 0, stream, fc, (const TriRec *)nullptr,
                            (const uint32_t *)nullptr, (const uint8_t *)nullptr, sc->d_quads.as<QuadRec>(),
@@ -315,7 +328,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                            (const Counters *)ctr, sc->quad_cap, sc->d_quad_count.as<uint32_t>(),
                            sc->d_quad_offset.as<uint32_t>(), sc->d_quad_items.as<uint32_t>(), sc->quad_item_cap);
     }
-    HIP_TRY(hipEventRecord(sc->ev[2], stream));
+    HIP_TRY(hipEventRecord(sc->ev[5], stream));
 
     // ---- visibility: coverage, z, stencil
     hipLaunchKernelGGL(k_tile_raster, dim3(blocks_for(n_tiles, 256 / WAVE)), dim3(256), 0, stream, fc,
@@ -323,7 +336,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                        sc->d_tri_items.as<uint32_t>(), sc->tri_item_cap, sc->d_quads.as<QuadRec>(),
                        sc->d_quad_offset.as<uint32_t>(), sc->d_quad_items.as<uint32_t>(), sc->quad_item_cap,
                        sc->d_z.as<double>(), sc->d_winner.as<int32_t>(), sc->d_stencil.as<int16_t>(), ctr);
-    HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    HIP_TRY(hipEventRecord(sc->ev[6], stream));
 
     // ---- deferred shading + finalise
     ShadeArgs sa;
@@ -336,11 +349,12 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     sa.out = d_out;
     const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(band_px, 256)), dim3(256), 0, stream, fc, sa);
-    HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    HIP_TRY(hipEventRecord(sc->ev[7], stream));
     HIP_TRY(hipMemcpyAsync(sc->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipGetLastError());
     sc->last_frame = *fr;
     sc->have_frame = true;
+    sc->frames_enqueued += 1;
     return MR_OK;
 }
 
@@ -358,10 +372,10 @@ int collect(mr_scene *sc, bool with_copy)
     sc->n_silhouette = (int)c.n_quads;
     float ms = 0;
     auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, sc->ev[a], sc->ev[b]); return ms; };
-    s.gpu_ms_geometry = span(0, 1); s.gpu_ms_binning = span(1, 2); s.gpu_ms_raster = span(2, 3);
-    s.gpu_ms_shade = span(3, 4);
-    s.gpu_ms_copy = with_copy ? span(4, 5) : 0.f;
-    s.gpu_ms_total = span(0, with_copy ? 5 : 4);
+    s.gpu_ms_geometry = span(0, 3); s.gpu_ms_binning = span(3, 5); s.gpu_ms_raster = span(5, 6);
+    s.gpu_ms_shade = span(6, 7);
+    s.gpu_ms_copy = with_copy ? span(7, 8) : 0.f;
+    s.gpu_ms_total = span(0, with_copy ? 8 : 7);
     if (c.overflow) {
         if (c.overflow & 1u) { sc->tri_item_cap = c.tri_bin_total + c.tri_bin_total / 2 + 1024; }
         if (c.overflow & 2u) { sc->quad_item_cap = c.quad_bin_total + c.quad_bin_total / 2 + 1024; }
@@ -441,7 +455,7 @@ void mr_scene_destroy(mr_scene *sc)
                        &sc->d_quad_items, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
     for (DevBuf *b : bufs) b->release();
     if (sc->events_ok) {
-        for (auto &e : sc->ev) (void)hipEventDestroy(e);
+        for (auto &set : sc->ev_ring) for (auto &e : set) (void)hipEventDestroy(e);
         (void)hipHostFree(sc->h_counters);
     }
     delete sc;
@@ -534,7 +548,7 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
         HIP_TRY(sc->d_out.ensure(band_bytes));
         if ((rc = enqueue_frame(sc, fr, sc->d_out.as<uint8_t>(), g_stream))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipEventRecord(sc->ev[5], g_stream));
+        HIP_TRY(hipEventRecord(sc->ev[8], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         rc = collect(sc, true);
         if (rc == MR_OK) {
@@ -565,6 +579,28 @@ int mr_get_stats(mr_scene *sc, mr_stats *stats)
     if (rc == MR_E_OVERFLOW)
         return fail(MR_E_OVERFLOW, "the last frame overflowed a work list (now grown): render it again");
     return rc;
+}
+
+int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
+{
+    if (!sc || !out_ms || cap < MR_N_KERNEL_TIMES) return fail(MR_E_INVALID, "need room for MR_N_KERNEL_TIMES floats");
+    if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    HIP_TRY(hipDeviceSynchronize());
+    const uint64_t have = std::min<uint64_t>(sc->frames_enqueued, mr_scene::EVENT_RING);
+    const uint64_t n = std::min<uint64_t>(have, n_frames > 0 ? (uint64_t)n_frames : 1);
+    double acc[MR_N_KERNEL_TIMES] = {};
+    for (uint64_t i = 0; i < n; ++i) {
+        hipEvent_t *ev = sc->ev_ring[(sc->frames_enqueued - 1 - i) % mr_scene::EVENT_RING];
+        float ms;
+        for (int k = 0; k < 7; ++k) {
+            ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            acc[k] += ms;
+        }
+        ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[7]);
+        acc[7] += ms;
+    }
+    for (int k = 0; k < MR_N_KERNEL_TIMES; ++k) out_ms[k] = (float)(acc[k] / (double)n);
+    return (int)n;
 }
 
 int mr_read_z(mr_scene *sc, double *out)
