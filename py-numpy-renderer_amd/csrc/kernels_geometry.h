@@ -97,10 +97,12 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
 
     TriRec t;
     double xs[3] = { A.sx, B.sx, C.sx }, ys[3] = { A.sy, B.sy, C.sy };
-    if (!bound_box(xs, ys, 3, fc.width, fc.height, t.x0, t.x1, t.y0, t.y1)) {
+    int bx0, bx1, by0, by1;
+    if (!bound_box(xs, ys, 3, fc.width, fc.height, bx0, bx1, by0, by1)) {
         status[f] = FACE_EMPTY_Z;
         return;
     }
+    t.x0 = (int16_t)bx0; t.x1 = (int16_t)bx1; t.y0 = (int16_t)by0; t.y1 = (int16_t)by1;
     t.ax = A.sx; t.ay = A.sy;
     t.v0x = B.sx - A.sx; t.v0y = B.sy - A.sy;
     t.v1x = C.sx - A.sx; t.v1y = C.sy - A.sy;
@@ -111,21 +113,21 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     if (den == 0) { status[f] = FACE_EMPTY_B; return; }
     t.inv_den = 1.0f / den;
     t.zl0 = A.zlin; t.zl1 = B.zlin; t.zl2 = C.zlin;
-    t.dp0 = A.depth; t.dp1 = B.depth; t.dp2 = C.depth;
-    long long box = (long long)(t.x1 - t.x0) * (long long)(t.y1 - t.y0);
+    t.pad[0] = t.pad[1] = 0;
+    long long box = (long long)(bx1 - bx0) * (long long)(by1 - by0);
     t.flags = ((ff & FF_CLIP) ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u);
     t.face = f;
     status[f] = FACE_OK;
     if (box <= 0) { status[f] = FACE_CLIPPED; return; }    // no sample inside the box
     tris[f] = t;
+    TriClip &cl = clips[f];
+    cl.dp[0] = A.depth; cl.dp[1] = B.depth; cl.dp[2] = C.depth;
     if (ff & FF_CLIP) {
-        TriClip cl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             cl.clip[0][j] = A.clip[j]; cl.clip[1][j] = B.clip[j]; cl.clip[2][j] = C.clip[j];
             cl.clipd[0][j] = A.clipd[j]; cl.clipd[1][j] = B.clipd[j]; cl.clipd[2][j] = C.clipd[j];
         }
-        clips[f] = cl;
     }
     uint32_t slot = atomicAdd(&ctr->n_valid_tris, 1u);
     valid_list[slot] = (uint32_t)f;
@@ -165,7 +167,7 @@ k_tri_count(const FrameConst fc, const uint32_t *__restrict__ valid_list, TriRec
         if (do_clip && __ballot(ok)) {
             if (ok) {
                 double p[3];
-                persp_bary(t, u, v, w, single, p);
+                persp_bary(clips[f].dp, u, v, w, single, p);
                 ok = inside_clip(p, clips[f].clip) && inside_clip(p, clips[f].clipd);
             }
         }
@@ -280,32 +282,36 @@ k_silhouette(const FrameConst fc, const uint32_t *__restrict__ edge_offset, cons
     if (n < 3) return;
 
     QuadRec q;
-    double sz[MAX_POLY];
+    double sx[MAX_POLY], sy[MAX_POLY], sz[MAX_POLY];
     for (int i = 0; i < n; ++i) {
         double c4[4], nd[4];
         for (int j = 0; j < 4; ++j) c4[j] = row_times_col(poly[i], fc.mvp, j);
         for (int j = 0; j < 4; ++j) nd[j] = c4[j] / c4[3];
-        q.sx[i] = row_times_col(nd, fc.viewport, 0);
-        q.sy[i] = row_times_col(nd, fc.viewport, 1);
+        sx[i] = row_times_col(nd, fc.viewport, 0);
+        sy[i] = row_times_col(nd, fc.viewport, 1);
         sz[i] = row_times_col(nd, fc.viewport, 2);
     }
-    for (int i = 0; i < n; ++i) {
-        int k1 = (i + 1 == n) ? 0 : i + 1;
-        q.ex[i] = q.sx[k1] - q.sx[i];
-        q.ey[i] = q.sy[k1] - q.sy[i];
+    for (int i = 0; i < MAX_POLY; ++i) {
+        const int k1 = (i + 1 == n) ? 0 : i + 1;
+        const bool used = i < n;
+        q.e[i].sx = used ? sx[i] : 0.0;
+        q.e[i].sy = used ? sy[i] : 0.0;
+        q.e[i].ex = used ? sx[k1] - sx[i] : 0.0;
+        q.e[i].ey = used ? sy[k1] - sy[i] : 0.0;
     }
-    for (int i = n; i < MAX_POLY; ++i) { q.sx[i] = q.sy[i] = q.ex[i] = q.ey[i] = 0; }
-    double ab[3] = { q.sx[0] - q.sx[1], q.sy[0] - q.sy[1], sz[0] - sz[1] };
-    double ac[3] = { q.sx[0] - q.sx[2], q.sy[0] - q.sy[2], sz[0] - sz[2] };
+    double ab[3] = { sx[0] - sx[1], sy[0] - sy[1], sz[0] - sz[1] };
+    double ac[3] = { sx[0] - sx[2], sy[0] - sy[2], sz[0] - sz[2] };
     q.nx = ab[1] * ac[2] - ab[2] * ac[1];
     q.ny = ab[2] * ac[0] - ab[0] * ac[2];
     q.nz = ab[0] * ac[1] - ab[1] * ac[0];
     q.is_front = q.nz < 0;
-    q.d = chain3(-q.sx[0], -q.sy[0], -sz[0], q.nx, q.ny, q.nz);
+    q.d = chain3(-sx[0], -sy[0], -sz[0], q.nx, q.ny, q.nz);
     q.n = n;
     q.edge = e;
-    q.pad = 0;
-    if (!bound_box(q.sx, q.sy, n, fc.width, fc.height, q.x0, q.x1, q.y0, q.y1)) return;
+    q.pad[0] = q.pad[1] = q.pad[2] = 0;
+    int bx0, bx1, by0, by1;
+    if (!bound_box(sx, sy, n, fc.width, fc.height, bx0, bx1, by0, by1)) return;
+    q.x0 = (int16_t)bx0; q.x1 = (int16_t)bx1; q.y0 = (int16_t)by0; q.y1 = (int16_t)by1;
     uint32_t slot = atomicAdd(&ctr->n_quads_drawn, 1u);
     if (slot >= quad_cap) { atomicOr(&ctr->overflow, 4u); return; }
     quads[slot] = q;

@@ -14,6 +14,7 @@ namespace mr {
 
 struct ShadeArgs {
     const TriRec *tris;
+    const TriClip *clips;
     const int32_t *faces;
     const uint8_t *face_flags;
     const double *verts;
@@ -125,7 +126,7 @@ k_shade(const FrameConst fc, const ShadeArgs a)
         float u, v, w;
         tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
         double p[3];
-        persp_bary(t, u, v, w, false, p);
+        persp_bary(a.clips[f].dp, u, v, w, false, p);
 
         double color[3];
         if (mat.tex_kd >= 0) {

@@ -90,9 +90,9 @@ struct mr_scene {
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
     // ---- per-frame work buffers
     DevBuf d_vout, d_tris, d_clips, d_status, d_lit, d_valid, d_quads, d_sil, d_counters;
-    DevBuf d_tri_count, d_tri_offset, d_tri_items, d_quad_count, d_quad_offset, d_quad_items;
+    DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_tile_stats;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
-    uint32_t tri_item_cap = 0, quad_item_cap = 0, quad_cap = 0;
+    uint32_t item_cap = 0, work_cap = 0, quad_cap = 0;
 
     mr::Counters *h_counters = nullptr;      // pinned
     // Event marks of the last EVENT_RING frames (frames are enqueued without host syncs, so a
@@ -182,7 +182,7 @@ int commit(mr_scene *sc)
 int validate_frame(const mr_frame_desc *fr)
 {
     if (!fr) return fail(MR_E_INVALID, "frame descriptor is NULL");
-    if (fr->width <= 0 || fr->height <= 0 || fr->width > 32768 || fr->height > 32768)
+    if (fr->width <= 0 || fr->height <= 0 || fr->width > 32767 || fr->height > 32767)
         return fail(MR_E_INVALID, "resolution out of range");
     if (fr->system != 1 && fr->system != -1) return fail(MR_E_INVALID, "system must be +1 (RH) or -1 (LH)");
     if (fr->row_begin < 0 || fr->row_end > fr->height || fr->row_begin >= fr->row_end)
@@ -240,8 +240,8 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     const size_t nF = (size_t)std::max(fc.n_faces, 1), nV = (size_t)std::max(fc.n_vertices, 1);
 
     if (sc->quad_cap == 0) sc->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
-    if (sc->tri_item_cap == 0) sc->tri_item_cap = (uint32_t)std::max<size_t>(4 * nF + 4 * (size_t)n_tiles, 1u << 20);
-    if (sc->quad_item_cap == 0) sc->quad_item_cap = 1u << 22;
+    if (sc->item_cap == 0) sc->item_cap = (uint32_t)std::max<size_t>(4 * nF + 8 * (size_t)n_tiles, 1u << 22);
+    if (sc->work_cap == 0) sc->work_cap = 1u << 18;
 
     HIP_TRY(sc->d_vout.ensure(nV * sizeof(VertexOut)));
     HIP_TRY(sc->d_tris.ensure(nF * sizeof(TriRec)));
@@ -252,12 +252,11 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     HIP_TRY(sc->d_quads.ensure((size_t)sc->quad_cap * sizeof(QuadRec)));
     HIP_TRY(sc->d_sil.ensure((size_t)sc->quad_cap * 3 * sizeof(int32_t)));
     HIP_TRY(sc->d_counters.ensure(sizeof(Counters)));
-    HIP_TRY(sc->d_tri_count.ensure((size_t)(n_tiles + 1) * 4));
-    HIP_TRY(sc->d_tri_offset.ensure((size_t)(n_tiles + 1) * 4));
-    HIP_TRY(sc->d_quad_count.ensure((size_t)(n_tiles + 1) * 4));
-    HIP_TRY(sc->d_quad_offset.ensure((size_t)(n_tiles + 1) * 4));
-    HIP_TRY(sc->d_tri_items.ensure((size_t)sc->tri_item_cap * 4));
-    HIP_TRY(sc->d_quad_items.ensure((size_t)sc->quad_item_cap * 4));
+    HIP_TRY(sc->d_bin_count.ensure((size_t)(2 * n_tiles + 1) * 4));
+    HIP_TRY(sc->d_bin_offset.ensure((size_t)(2 * n_tiles + 1) * 4));
+    HIP_TRY(sc->d_items.ensure((size_t)sc->item_cap * 4));
+    HIP_TRY(sc->d_work.ensure((size_t)sc->work_cap * sizeof(uint2)));
+    HIP_TRY(sc->d_tile_stats.ensure((size_t)n_tiles * TILE_STATS * 4));
     HIP_TRY(sc->d_z.ensure(npx * sizeof(double)));
     HIP_TRY(sc->d_winner.ensure(npx * sizeof(int32_t)));
     HIP_TRY(sc->d_stencil.ensure(npx * sizeof(int16_t)));
@@ -272,9 +271,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     Counters *ctr = sc->d_counters.as<Counters>();
     HIP_TRY(hipEventRecord(sc->ev[0], stream));
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_tri_count.p, 0, (size_t)(n_tiles + 1) * 4, stream));
-    HIP_TRY(hipMemsetAsync(sc->d_quad_count.p, 0, (size_t)(n_tiles + 1) * 4, stream));
-    HIP_TRY(hipMemsetAsync(sc->d_quad_offset.p, 0, (size_t)(n_tiles + 1) * 4, stream));
+    HIP_TRY(hipMemsetAsync(sc->d_bin_count.p, 0, (size_t)(2 * n_tiles + 1) * 4, stream));
 
     // ---- geometry
     if (fc.n_vertices > 0)
@@ -300,47 +297,38 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                            sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
     HIP_TRY(hipEventRecord(sc->ev[3], stream));
 
-    // ---- binning: count, scan, fill
-    const unsigned tri_blocks = blocks_for(fc.n_faces, 256);
-    const unsigned quad_blocks = blocks_for(std::min<long long>(fc.n_edges, sc->quad_cap), 256);
-    if (fc.n_faces > 0)
-        hipLaunchKernelGGL((k_bin<false, false>), dim3(tri_blocks), dim3(256), 0, stream, fc, sc->d_tris.as<TriRec>(),
-                           sc->d_valid.as<uint32_t>(), sc->d_status.as<uint8_t>(), (const QuadRec *)nullptr,
-                           (const Counters *)ctr, sc->quad_cap, sc->d_tri_count.as<uint32_t>(),
-                           (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_tri_count.as<uint32_t>(),
-                       sc->d_tri_offset.as<uint32_t>(), n_tiles, sc->tri_item_cap, &ctr->tri_bin_total, 1u, ctr);
-    if (fc.n_faces > 0)
-        hipLaunchKernelGGL((k_bin<true, false>), dim3(tri_blocks), dim3(256), 0, stream, fc, sc->d_tris.as<TriRec>(),
-                           sc->d_valid.as<uint32_t>(), sc->d_status.as<uint8_t>(), (const QuadRec *)nullptr,
-                           (const Counters *)ctr, sc->quad_cap, sc->d_tri_count.as<uint32_t>(),
-                           sc->d_tri_offset.as<uint32_t>(), sc->d_tri_items.as<uint32_t>(), sc->tri_item_cap);
+    // ---- binning: classify + count, large-primitive count, scan, fill, large-primitive fill
+    BinArgs ba;
+    ba.tris = sc->d_tris.as<TriRec>(); ba.valid_list = sc->d_valid.as<uint32_t>();
+    ba.status = sc->d_status.as<uint8_t>(); ba.quads = sc->d_quads.as<QuadRec>();
+    ba.ctr = ctr; ba.quad_cap = sc->quad_cap;
+    ba.bin_count = sc->d_bin_count.as<uint32_t>(); ba.bin_offset = sc->d_bin_offset.as<uint32_t>();
+    ba.items = sc->d_items.as<uint32_t>(); ba.item_cap = sc->item_cap;
+    ba.work = sc->d_work.as<uint2>(); ba.work_cap = sc->work_cap;
+    const long long n_prims_max = (long long)fc.n_faces + (shadows ? std::min<long long>(fc.n_edges, sc->quad_cap) : 0);
+    const unsigned classify_blocks = blocks_for(n_prims_max, 256);
+    const unsigned large_blocks = 1024;      // grid-stride over the work items, 4 wavefronts per block
+    hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
+    hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
     HIP_TRY(hipEventRecord(sc->ev[4], stream));
-    if (shadows && fc.n_edges > 0) {
-        hipLaunchKernelGGL((k_bin<false, true>), dim3(quad_blocks), dim3(256), 0, stream, fc, (const TriRec *)nullptr,
-                           (const uint32_t *)nullptr, (const uint8_t *)nullptr, sc->d_quads.as<QuadRec>(),
-                           (const Counters *)ctr, sc->quad_cap, sc->d_quad_count.as<uint32_t>(),
-                           (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
-        hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_quad_count.as<uint32_t>(),
-                           sc->d_quad_offset.as<uint32_t>(), n_tiles, sc->quad_item_cap, &ctr->quad_bin_total, 2u, ctr);
-        hipLaunchKernelGGL((k_bin<true, true>), dim3(quad_blocks), dim3(256), 0, stream, fc, (const TriRec *)nullptr,
-                           (const uint32_t *)nullptr, (const uint8_t *)nullptr, sc->d_quads.as<QuadRec>(),
-                           (const Counters *)ctr, sc->quad_cap, sc->d_quad_count.as<uint32_t>(),
-                           sc->d_quad_offset.as<uint32_t>(), sc->d_quad_items.as<uint32_t>(), sc->quad_item_cap);
-    }
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_bin_count.as<uint32_t>(),
+                       sc->d_bin_offset.as<uint32_t>(), n_tiles, sc->item_cap, ctr);
+    hipLaunchKernelGGL((k_bin_classify<true>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
+    hipLaunchKernelGGL((k_bin_large<true>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
     HIP_TRY(hipEventRecord(sc->ev[5], stream));
 
     // ---- visibility: coverage, z, stencil
     hipLaunchKernelGGL(k_tile_raster, dim3(blocks_for(n_tiles, 256 / WAVE)), dim3(256), 0, stream, fc,
-                       sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(), sc->d_tri_offset.as<uint32_t>(),
-                       sc->d_tri_items.as<uint32_t>(), sc->tri_item_cap, sc->d_quads.as<QuadRec>(),
-                       sc->d_quad_offset.as<uint32_t>(), sc->d_quad_items.as<uint32_t>(), sc->quad_item_cap,
-                       sc->d_z.as<double>(), sc->d_winner.as<int32_t>(), sc->d_stencil.as<int16_t>(), ctr);
+                       sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(), sc->d_quads.as<QuadRec>(),
+                       sc->d_bin_offset.as<uint32_t>(), sc->d_items.as<uint32_t>(), sc->item_cap,
+                       sc->d_z.as<double>(), sc->d_winner.as<int32_t>(), sc->d_stencil.as<int16_t>(),
+                       sc->d_tile_stats.as<uint32_t>());
+    hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, stream, sc->d_tile_stats.as<uint32_t>(), n_tiles, ctr);
     HIP_TRY(hipEventRecord(sc->ev[6], stream));
 
     // ---- deferred shading + finalise
     ShadeArgs sa;
-    sa.tris = sc->d_tris.as<TriRec>(); sa.faces = sc->d_faces.as<int32_t>();
+    sa.tris = sc->d_tris.as<TriRec>(); sa.clips = sc->d_clips.as<TriClip>(); sa.faces = sc->d_faces.as<int32_t>();
     sa.face_flags = sc->d_face_flags.as<uint8_t>(); sa.verts = sc->d_verts.as<double>();
     sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
     sa.materials = sc->d_materials.as<Material>(); sa.textures = sc->d_textures.as<Texture>();
@@ -377,8 +365,9 @@ int collect(mr_scene *sc, bool with_copy)
     s.gpu_ms_copy = with_copy ? span(7, 8) : 0.f;
     s.gpu_ms_total = span(0, with_copy ? 8 : 7);
     if (c.overflow) {
-        if (c.overflow & 1u) { sc->tri_item_cap = c.tri_bin_total + c.tri_bin_total / 2 + 1024; }
-        if (c.overflow & 2u) { sc->quad_item_cap = c.quad_bin_total + c.quad_bin_total / 2 + 1024; }
+        const uint32_t entries = c.tri_bin_total + c.quad_bin_total;
+        if (c.overflow & 1u) { sc->item_cap = entries + entries / 2 + 1024; }
+        if (c.overflow & 2u) { sc->work_cap = c.n_work + c.n_work / 2 + 1024; }
         if (c.overflow & 4u) { sc->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, sc->quad_cap * 2); }
         if (c.n_quads > sc->quad_cap) sc->quad_cap = c.n_quads + c.n_quads / 2 + 64;
         return MR_E_OVERFLOW;
@@ -439,7 +428,7 @@ int mr_scene_clear(mr_scene *sc)
     sc->verts.clear(); sc->uv.clear(); sc->normals.clear(); sc->faces.clear(); sc->face_flags.clear();
     sc->materials.clear(); sc->models.clear(); sc->edge_offset.clear(); sc->edge_inc.clear();
     sc->dirty = true; sc->have_frame = false;
-    sc->tri_item_cap = sc->quad_item_cap = sc->quad_cap = 0;
+    sc->item_cap = sc->work_cap = sc->quad_cap = 0;
     return MR_OK;
 }
 
@@ -451,8 +440,7 @@ void mr_scene_destroy(mr_scene *sc)
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
                        &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_vout, &sc->d_tris, &sc->d_clips,
                        &sc->d_status, &sc->d_lit, &sc->d_valid, &sc->d_quads, &sc->d_sil, &sc->d_counters,
-                       &sc->d_tri_count, &sc->d_tri_offset, &sc->d_tri_items, &sc->d_quad_count, &sc->d_quad_offset,
-                       &sc->d_quad_items, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
+                       &sc->d_bin_count, &sc->d_bin_offset, &sc->d_items, &sc->d_work, &sc->d_tile_stats, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
     for (DevBuf *b : bufs) b->release();
     if (sc->events_ok) {
         for (auto &set : sc->ev_ring) for (auto &e : set) (void)hipEventDestroy(e);
@@ -533,7 +521,7 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
     sc->face_flags.insert(sc->face_flags.end(), (size_t)m->n_faces, ff);
     sc->models.push_back(mi);
     sc->dirty = true;
-    sc->tri_item_cap = sc->quad_item_cap = sc->quad_cap = 0;
+    sc->item_cap = sc->work_cap = sc->quad_cap = 0;
     return (int)sc->models.size() - 1;
 }
 

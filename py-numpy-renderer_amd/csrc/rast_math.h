@@ -82,13 +82,13 @@ __device__ __forceinline__ void tri_bary(const TriRec &t, double dpx, double dpy
 }
 
 // Face.screen_perspective (obj/core.py:155-160)
-__device__ __forceinline__ void persp_bary(const TriRec &t, float u, float v, float w, bool single,
+__device__ __forceinline__ void persp_bary(const double dp[3], float u, float v, float w, bool single,
                                            double p[3])
 {
-    double wc = rows_dot3(single, (double)u, (double)v, (double)w, t.dp0, t.dp1, t.dp2);
-    p[0] = ((double)u * t.dp0) / wc;
-    p[1] = ((double)v * t.dp1) / wc;
-    p[2] = ((double)w * t.dp2) / wc;
+    double wc = rows_dot3(single, (double)u, (double)v, (double)w, dp[0], dp[1], dp[2]);
+    p[0] = ((double)u * dp[0]) / wc;
+    p[1] = ((double)v * dp[1]) / wc;
+    p[2] = ((double)w * dp[2]) / wc;
 }
 
 // strict -w < x,y,z < w in one camera's clip space (obj/triangular.py:83-87)

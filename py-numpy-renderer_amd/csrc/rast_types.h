@@ -63,35 +63,42 @@ struct VertexOut {
     double zlin;                 // linearize_z(sz)
 };
 
-// Triangle set-up record consumed by the visibility and shading kernels
-// (the per-face constants of obj/transformation.py:12-32 and obj/triangular.py:96-97).
-struct TriRec {
+// Triangle set-up record walked by the visibility kernel: the per-face constants of
+// obj/transformation.py:12-32 and obj/triangular.py:96-97.  112 bytes = 7 x 16 so a lane can
+// fetch a whole record with seven 16-byte loads.
+struct alignas(16) TriRec {
     double ax, ay;               // screen position of corner a
     double v0x, v0y, v1x, v1y;   // b - a, c - a
     double zl0, zl1, zl2;        // linearised z of the corners
-    double dp0, dp1, dp2;        // 1/w of the corners
     float d00, d01, d11, inv_den;
-    int32_t x0, x1, y0, y1;      // half-open pixel box
+    int16_t x0, x1, y0, y1;      // half-open pixel box
     uint32_t flags;
     int32_t face;                // global face index
+    uint32_t pad[2];
 };
+static_assert(sizeof(TriRec) == 112, "TriRec layout");
 
-struct TriClip {
+// The rest of a face's set-up: 1/w of the corners (perspective-correct barycentrics,
+// obj/core.py:155-160) and, for models with clip=True, both cameras' clip-space corners.
+struct alignas(16) TriClip {
+    double dp[3];
+    double pad;
     double clip[3][4];
     double clipd[3][4];
 };
 
 // Shadow quad after extrusion, clipping and projection (obj/triangular.py:319-349).
-struct QuadRec {
-    double sx[MAX_POLY], sy[MAX_POLY];   // screen vertices
-    double ex[MAX_POLY], ey[MAX_POLY];   // edge vectors p[i+1] - p[i]
-    double nx, ny, nz, d;                // plane through the first three vertices
-    int32_t n;                           // vertex count (>= 3)
+struct alignas(16) QuadEdge { double sx, sy, ex, ey; };   // vertex i and the edge vector to vertex i+1
+struct alignas(16) QuadRec {
+    double nx, ny, nz, d;        // plane through the first three vertices
+    int16_t x0, x1, y0, y1;      // half-open pixel box
+    int32_t n;                   // vertex count (>= 3)
     int32_t is_front;
-    int32_t x0, x1, y0, y1;              // half-open pixel box
-    int32_t edge;                        // unique-edge index it came from
-    int32_t pad;
+    int32_t edge;                // unique-edge index it came from
+    uint32_t pad[3];
+    QuadEdge e[MAX_POLY];
 };
+static_assert(sizeof(QuadRec) == 64 + 32 * MAX_POLY, "QuadRec layout");
 
 struct Material {
     double kd[3];
@@ -110,8 +117,8 @@ struct Counters {
     unsigned long long frag_tri, frag_quad, covered_px, lit_px, stencil_updates;
     unsigned int n_valid_tris, n_quads, n_quads_drawn;
     unsigned int tri_bin_total, quad_bin_total;
-    unsigned int overflow;       // bit0: triangle bins, bit1: quad bins, bit2: quad list
-    unsigned int pad;
+    unsigned int n_work;         // (large primitive, 64-tile chunk) work items of the binning pass
+    unsigned int overflow;       // bit0: bin items, bit1: binning work list, bit2: quad list
 };
 
 }  // namespace mr
