@@ -176,6 +176,13 @@ int mr_read_face_status(mr_scene *scene, uint8_t *out_faces);  /* MR_FACE_* per 
  * (may exceed cap; only cap are written) or a negative error. */
 int mr_read_silhouette(mr_scene *scene, int32_t *out_triples, int32_t cap);
 
+/* Diagnostics: the visibility kernel's per-tile records of the last frame, 8 uint32 per tile:
+ * [0..4] triangle fragments, quad fragments, stencil updates, covered px, lit px; [5],[6] start
+ * and end of the tile's workgroup in 10 ns ticks (low 32 bits); [7] list sizes packed as
+ * small | big << 12 | quads << 22.  Returns the number of tiles (tiles are 16 x 16 px, row-major
+ * over the rendered band) or a negative error. */
+int mr_debug_read_tile_records(mr_scene *scene, uint32_t *out, int32_t cap_tiles);
+
 /* Human-readable description of the last error on this thread ("" if none). */
 const char *mr_last_error(void);
 

@@ -79,6 +79,7 @@ _PROTOTYPES = {
     "mr_read_frame_f32": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_face_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_silhouette": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "mr_debug_read_tile_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_last_error": (C.c_char_p, []),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
@@ -243,6 +244,13 @@ class DeviceRenderer:
 
     def read_frame_f32(self):
         return self._tap(self.lib.mr_read_frame_f32, np.float32, (3,))
+
+    def read_tile_records(self):
+        """Per-tile diagnostics of the visibility kernel: (n_tiles, 8) uint32, see mi355rast.h."""
+        n = _check(self.lib.mr_debug_read_tile_records(self.handle, (C.c_uint32 * 8)(), 0), "mr_debug_read_tile_records")
+        out = np.empty((max(n, 1), 8), dtype=np.uint32)
+        _check(self.lib.mr_debug_read_tile_records(self.handle, out.ctypes.data, n), "mr_debug_read_tile_records")
+        return out[:n]
 
     def read_silhouette(self):
         n = _check(self.lib.mr_read_silhouette(self.handle, None, 0), "mr_read_silhouette")

@@ -13,9 +13,11 @@
 namespace mr {
 
 __global__ void __launch_bounds__(256)
-k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out)
+k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
+         Counters *__restrict__ ctr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *ctr = Counters{};      // first kernel of the frame: every later one is stream-ordered after it
     if (i >= fc.n_vertices) return;
     double v[4] = { verts[i * 4 + 0], verts[i * 4 + 1], verts[i * 4 + 2], verts[i * 4 + 3] };
     VertexOut o;
@@ -33,6 +35,16 @@ k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__res
     o.sz = row_times_col(ndc, fc.viewport, 2);
     o.depth = depth;
     o.zlin = linearize_z(fc, o.sz);
+    // Strictly inside both cameras' clip volumes with a relative margin of 1e-12.  A fragment's
+    // clip coordinates are a non-negative combination of the corners' (weights u*dp/wc, all
+    // >= 0 when u,v,w >= 0 and every w > 0), evaluated with a few ulp (1e-16) of rounding, so
+    // when all three corners carry this flag the strict test of obj/triangular.py:85-87 cannot
+    // fail for any fragment of the face and need not be evaluated.
+    const double k = 1.0 - 1e-12;
+    const double wl = o.clip[3] * k, wd = o.clipd[3] * k;
+    o.safe = (fabs(o.clip[0]) < wl && fabs(o.clip[1]) < wl && fabs(o.clip[2]) < wl &&
+              fabs(o.clipd[0]) < wd && fabs(o.clipd[1]) < wd && fabs(o.clipd[2]) < wd) ? 1 : 0;
+    o.pad = 0;
     out[i] = o;
 }
 
@@ -115,14 +127,15 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     t.zl0 = A.zlin; t.zl1 = B.zlin; t.zl2 = C.zlin;
     t.pad[0] = t.pad[1] = 0;
     long long box = (long long)(bx1 - bx0) * (long long)(by1 - by0);
-    t.flags = ((ff & FF_CLIP) ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u);
+    const bool need_clip = (ff & FF_CLIP) && !(A.safe && B.safe && C.safe);
+    t.flags = (need_clip ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u);
     t.face = f;
     status[f] = FACE_OK;
     if (box <= 0) { status[f] = FACE_CLIPPED; return; }    // no sample inside the box
     tris[f] = t;
     TriClip &cl = clips[f];
     cl.dp[0] = A.depth; cl.dp[1] = B.depth; cl.dp[2] = C.depth;
-    if (ff & FF_CLIP) {
+    if (need_clip) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             cl.clip[0][j] = A.clip[j]; cl.clip[1][j] = B.clip[j]; cl.clip[2][j] = C.clip[j];
@@ -133,55 +146,92 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     valid_list[slot] = (uint32_t)f;
 }
 
-// One wavefront per set-up triangle: counts the fragments that survive coverage + clip over
-// the WHOLE frame (not just this device's band), stopping as soon as two are found.
-//   0 -> the reference returns CLIPPED for the face; 1 -> z = bar @ zlin is a dot.
+// Survivors of coverage + clip among the first `limit` samples of a triangle's pixel box, as
+// seen by one lane walking the box sample by sample (stops at two).
+struct CountResult { int found; unsigned int covered; };
+
+__device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const TriClip *clips,
+                                                int px, int py, bool &covered_in_band)
+{
+    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    float u, v, w;
+    tri_bary(t, (double)px, (double)py, single, u, v, w);
+    bool ok = u >= 0 && v >= 0 && w >= 0;
+    covered_in_band = ok && py >= fc.band_y0 && py < fc.band_y1;
+    if (ok && (t.flags & TF_CLIP)) {
+        const TriClip &c = clips[t.face];
+        double p[3];
+        persp_bary(c.dp, u, v, w, single, p);
+        ok = inside_clip(p, c.clip) && inside_clip(p, c.clipd);
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, Counters *ctr, int f, uint32_t flags,
+                                             int found, unsigned int covered)
+{
+    if (found == 0) {
+        // the face never reaches the visibility kernel: account for its fragments here
+        // (the fragment count is taken before the clip, obj/triangular.py:78)
+        status[f] = FACE_CLIPPED;
+        if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
+    } else if (found == 1) {
+        tris[f].flags = flags | TF_SINGLE_Z;
+    }
+}
+
+constexpr int COUNT_SMALL_BOX = 32;   // pixel boxes up to this size are walked by a single lane
+
+// Counts, per set-up triangle, the fragments that survive coverage + clip over the WHOLE frame
+// (not just this device's band), stopping as soon as two are found:
+//   0 -> the reference returns CLIPPED for the face; 1 -> z = bar @ zlin is a dot (TF_SINGLE_Z).
+// One lane per triangle: small pixel boxes (nearly all of a dense mesh) are walked by their
+// lane; the others are taken one at a time by the whole wavefront, 64 samples per step,
+// starting at the chunk that holds the centroid.
 __global__ void __launch_bounds__(256)
 k_tri_count(const FrameConst fc, const uint32_t *__restrict__ valid_list, TriRec *__restrict__ tris,
             const TriClip *__restrict__ clips, uint8_t *__restrict__ status, Counters *__restrict__ ctr)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
-    if (wave >= (int)ctr->n_valid_tris) return;
-    const int f = (int)valid_list[wave];
-    const TriRec t = tris[f];
-    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
-    const bool do_clip = (t.flags & TF_CLIP) != 0;
+    const bool valid = i < ctr->n_valid_tris;
+    const int f = valid ? (int)valid_list[i] : 0;
+    TriRec t = {};
+    if (valid) t = tris[f];
     const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
-    const long long total = (long long)bw * bh;
-    const long long chunks = (total + WAVE - 1) / WAVE;
-    // start at the 64-sample chunk holding the centroid: a well-shaped triangle is done after it
-    int cx = (int)(t.ax + (t.v0x + t.v1x) * (1.0 / 3.0)), cy = (int)(t.ay + (t.v0y + t.v1y) * (1.0 / 3.0));
-    cx = min(max(cx, t.x0), t.x1 - 1); cy = min(max(cy, t.y0), t.y1 - 1);
-    const long long first = ((long long)(cy - t.y0) * bw + (cx - t.x0)) / WAVE;
-    int found = 0;
-    unsigned int covered = 0;      // fragments before the clip, inside this device's band
-    for (long long c = 0; c < chunks && found < 2; ++c) {
-        long long idx = ((first + c) % chunks) * WAVE + lane;
-        bool ok = idx < total;
-        int px = t.x0 + (int)(idx % bw), py = t.y0 + (int)(idx / bw);
-        float u, v, w;
-        tri_bary(t, (double)px, (double)py, single, u, v, w);
-        ok = ok && u >= 0 && v >= 0 && w >= 0;
-        covered += (unsigned int)__popcll(__ballot(ok && py >= fc.band_y0 && py < fc.band_y1));
-        if (do_clip && __ballot(ok)) {
-            if (ok) {
-                double p[3];
-                persp_bary(clips[f].dp, u, v, w, single, p);
-                ok = inside_clip(p, clips[f].clip) && inside_clip(p, clips[f].clipd);
-            }
+    const int total = valid ? bw * bh : 0;
+    if (valid && total <= COUNT_SMALL_BOX) {
+        int found = 0;
+        unsigned int covered = 0;
+        for (int idx = 0; idx < total && found < 2; ++idx) {
+            bool cov;
+            found += sample_survives(fc, t, clips, t.x0 + idx % bw, t.y0 + idx / bw, cov) ? 1 : 0;
+            covered += cov ? 1u : 0u;
         }
-        found += __popcll(__ballot(ok));
+        count_finish(tris, status, ctr, f, t.flags, found, covered);
     }
-    if (lane == 0) {
-        if (found == 0) {
-            // the face never reaches the visibility kernel: account for its fragments here
-            // (the fragment count is taken before the clip, obj/triangular.py:78)
-            status[f] = FACE_CLIPPED;
-            if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
-        } else if (found == 1) {
-            tris[f].flags = t.flags | TF_SINGLE_Z;
+    unsigned long long big = __ballot(valid && total > COUNT_SMALL_BOX);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int fb = __shfl(f, src);
+        const TriRec tb = tris[fb];
+        const int w = tb.x1 - tb.x0;
+        const long long n = (long long)w * (tb.y1 - tb.y0);
+        const long long chunks = (n + WAVE - 1) / WAVE;
+        int cx = (int)(tb.ax + (tb.v0x + tb.v1x) * (1.0 / 3.0)), cy = (int)(tb.ay + (tb.v0y + tb.v1y) * (1.0 / 3.0));
+        cx = min(max(cx, (int)tb.x0), tb.x1 - 1); cy = min(max(cy, (int)tb.y0), tb.y1 - 1);
+        const long long first = ((long long)(cy - tb.y0) * w + (cx - tb.x0)) / WAVE;
+        int found = 0;
+        unsigned int covered = 0;
+        for (long long c = 0; c < chunks && found < 2; ++c) {
+            const long long idx = ((first + c) % chunks) * WAVE + lane;
+            bool cov = false, ok = false;
+            if (idx < n) ok = sample_survives(fc, tb, clips, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w), cov);
+            covered += (unsigned int)__popcll(__ballot(cov));
+            found += __popcll(__ballot(ok));
         }
+        if (lane == 0) count_finish(tris, status, ctr, fb, tb.flags, found, covered);
     }
 }
 

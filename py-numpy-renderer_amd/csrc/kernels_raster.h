@@ -1,22 +1,33 @@
-// kernels_raster.h -- screen-tile binning and the tile-owner visibility kernel.
+// kernels_raster.h -- screen-tile binning and the visibility kernel.
 //
 // Design (MI355X-first, not a port of the reference's per-face loops): the frame is cut into
-// 8x8-pixel tiles, one 64-lane wavefront owns one tile and keeps its z / winner / stencil in
-// registers while it walks the tile's primitive lists.  No atomics touch the frame buffers and
-// every buffer is written exactly once, coalesced.  The reference's sequential semantics
-// (obj/triangular.py:101-118: later face wins on z ties) are reproduced order-free by
-// resolving ties on the face index.
+// 16x16-pixel tiles; one 256-thread workgroup owns one tile and keeps the tile's z-buffer and
+// winner map in LDS, so the frame buffers see no atomics and are written exactly once,
+// coalesced.  Measured on MI355X (tools/micro/atomic_bench.hip): scattered 64-bit global
+// atomics run at 24 G/s, LDS atomics at 1 900 G/s.
+//
+// Inside a tile the work is parallelised the way that fits the primitive:
+//   * small (triangle, tile) pairs -- a dense mesh's triangles cover a handful of samples --
+//     one TRIANGLE per thread: the thread walks the few samples of the pixel box and does an
+//     LDS atomicMin on the order-preserving key of z, then (second sweep) an LDS atomicMax of
+//     its face index where its z is the tile's final z;
+//   * big pairs (a floor triangle) and shadow quads one PIXEL per thread, the primitive
+//     records staged 64 at a time in registers and broadcast with v_readlane.
+// The reference's sequential rule (obj/triangular.py:101-118: a fragment writes when
+// zbuf >= z, so the last face in order wins ties) is reproduced order-free: smallest z, and
+// among equal z the largest face index.
 //
 //   k_bin_classify<FILL>  one lane per primitive (triangles, then shadow quads): primitives
 //                         touching a few tiles are binned by their lane; large ones are cut into
 //                         work items of 64 tiles
 //   k_bin_large<FILL>     one wavefront per work item, one tile per lane
-//   k_scan_bins           exclusive scan of the per-tile counts (single workgroup, coalesced)
-//   k_tile_raster         coverage + clip + z for triangles, then the stencil count of the
-//                         shadow quads against the final z (obj/triangular.py:72-118, 335-368)
+//   k_scan_bins           exclusive scan of the per-(class, tile) counts (one workgroup)
+//   k_tile_raster         coverage + clip + z + winner for triangles, then the stencil count
+//                         of the shadow quads against the final z (obj/triangular.py:72-118, 335-368)
+//   k_reduce_tile_stats   sums the per-tile fragment counts
 //
-// Bin layout: count/offset arrays hold 2 * n_tiles entries, triangles' bins first, then the
-// quads' bins; one scan lays both out in a single item array.
+// Bin layout: count/offset arrays hold BIN_CLASSES * n_tiles entries (small triangle pairs,
+// big triangle pairs, quads); one scan lays all of them out in a single item array.
 #pragma once
 
 #include "rast_math.h"
@@ -64,41 +75,58 @@ struct BinArgs {
     const QuadRec *quads;
     Counters *ctr;
     uint32_t quad_cap;
-    uint32_t *bin_count;          // [2 * n_tiles]
-    const uint32_t *bin_offset;   // [2 * n_tiles + 1]
+    uint32_t *bin_count;          // [BIN_CLASSES * n_tiles]
+    const uint32_t *bin_offset;   // [BIN_CLASSES * n_tiles + 1]
     uint32_t *items;
     uint32_t item_cap;
     uint2 *work;                  // (unified primitive index, chunk)
     uint32_t work_cap;
+    uint4 *quad_work;             // (tile, first item, count, -) of k_tile_quads
+    uint32_t quad_work_cap;
 };
 
 constexpr int TILE_STATS = 5;     // per-tile partial counters written by k_tile_raster
+constexpr int TILE_REC = 8;       // words per tile record: the counters, then start / end time (10 ns ticks) and list sizes
+constexpr int QUAD_BATCH = 16;     // shadow quads per work item of k_tile_quads
 constexpr int BIN_SMALL = 4;      // primitives touching <= this many tiles are binned by their own lane
 
-// unified primitive index -> record, tile span
+// unified primitive index -> record, pixel box, tile span
+struct PrimBox { int x0, x1, y0, y1; };
+
 __device__ __forceinline__ bool prim_span(const FrameConst &fc, const BinArgs &a, uint32_t u, uint32_t n_tris,
-                                          uint32_t n_quads, bool &is_quad, uint32_t &id, TileSpan &sp)
+                                          uint32_t n_quads, bool &is_quad, uint32_t &id, PrimBox &pb, TileSpan &sp)
 {
     if (u < n_tris) {
         is_quad = false;
         id = a.valid_list[u];
         const TriRec &t = a.tris[id];
-        return a.status[id] == FACE_OK && tile_span(fc, t.x0, t.x1, t.y0, t.y1, sp);
+        pb = { t.x0, t.x1, t.y0, t.y1 };
+        return a.status[id] == FACE_OK && tile_span(fc, pb.x0, pb.x1, pb.y0, pb.y1, sp);
     }
     if (u < n_tris + n_quads) {
         is_quad = true;
         id = u - n_tris;
         const QuadRec &q = a.quads[id];
-        return tile_span(fc, q.x0, q.x1, q.y0, q.y1, sp);
+        pb = { q.x0, q.x1, q.y0, q.y1 };
+        return tile_span(fc, pb.x0, pb.x1, pb.y0, pb.y1, sp);
     }
     return false;
 }
 
-template <bool FILL>
-__device__ __forceinline__ void bin_emit(const FrameConst &fc, const BinArgs &a, bool is_quad, uint32_t id,
-                                         int tx, int ty)
+// bin class of a (primitive, tile) pair
+__device__ __forceinline__ int pair_class(const FrameConst &fc, bool is_quad, const PrimBox &pb, int tx, int ty)
 {
-    const uint32_t bin = (is_quad ? (uint32_t)(fc.tiles_x * fc.tiles_y) : 0u) + (uint32_t)ty * fc.tiles_x + tx;
+    if (is_quad) return 2;
+    const int gx = tx * TILE_W, gy = (ty + fc.tile_y0) * TILE_H;
+    const int w = min(pb.x1, gx + TILE_W) - max(pb.x0, gx);
+    const int h = min(min(pb.y1, gy + TILE_H), fc.band_y1) - max(max(pb.y0, gy), fc.band_y0);
+    return w * h > BIG_PAIR_PX ? 1 : 0;
+}
+
+template <bool FILL>
+__device__ __forceinline__ void bin_emit(const FrameConst &fc, const BinArgs &a, int cls, uint32_t id, int tx, int ty)
+{
+    const uint32_t bin = (uint32_t)cls * (uint32_t)(fc.tiles_x * fc.tiles_y) + (uint32_t)ty * fc.tiles_x + tx;
     const uint32_t pos = atomicAdd(&a.bin_count[bin], 1u);
     if (FILL) {
         const uint32_t at = a.bin_offset[bin] + pos;
@@ -116,29 +144,52 @@ k_bin_classify(const FrameConst fc, const BinArgs a)
     bool is_quad = false;
     uint32_t id = 0;
     TileSpan sp = { 0, 0, 0, 0 };
-    const bool valid = prim_span(fc, a, u, n_tris, n_quads, is_quad, id, sp);
+    PrimBox pb = { 0, 0, 0, 0 };
+    const bool valid = prim_span(fc, a, u, n_tris, n_quads, is_quad, id, pb, sp);
     const int ntiles = valid ? (sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0) : 0;
     if (valid && ntiles <= BIN_SMALL) {
         for (int ty = sp.ty0; ty < sp.ty1; ++ty)
             for (int tx = sp.tx0; tx < sp.tx1; ++tx)
                 if (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0))
-                    bin_emit<FILL>(fc, a, is_quad, id, tx, ty);
+                    bin_emit<FILL>(fc, a, pair_class(fc, is_quad, pb, tx, ty), id, tx, ty);
     }
-    if (FILL) return;             // the work list of the count pass is reused by the fill pass
-    // large primitives: one work item per 64 tiles of the span, written by the whole wavefront
-    unsigned long long big = __ballot(valid && ntiles > BIN_SMALL);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t pu = __shfl(u, src);
-        const int chunks = (__shfl(ntiles, src) + WAVE - 1) / WAVE;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.ctr->n_work, (uint32_t)chunks);
-        base = __shfl(base, 0);
-        for (int c = lane; c < chunks; c += WAVE) {
-            if (base + c < a.work_cap) a.work[base + c] = make_uint2(pu, (uint32_t)c);
-            else atomicOr(&a.ctr->overflow, 2u);
+    if (FILL) {
+        // (fill pass: the offsets exist now) thread u also cuts tile u's shadow-quad list into
+        // work items of at most QUAD_BATCH quads for k_tile_quads, so that the tiles under a
+        // dense shadow volume are shared out over many workgroups
+        const uint32_t n_tiles = (uint32_t)(fc.tiles_x * fc.tiles_y);
+        if (u < n_tiles) {
+            const uint32_t first = a.bin_offset[2 * n_tiles + u], cnt = a.bin_offset[2 * n_tiles + u + 1] - first;
+            if (cnt) {
+                const uint32_t nb = (cnt + QUAD_BATCH - 1) / QUAD_BATCH;
+                const uint32_t at = atomicAdd(&a.ctr->n_quad_work, nb);
+                for (uint32_t b = 0; b < nb; ++b) {
+                    if (at + b < a.quad_work_cap)
+                        a.quad_work[at + b] = make_uint4(u, first + b * QUAD_BATCH, min((uint32_t)QUAD_BATCH, cnt - b * QUAD_BATCH), 0u);
+                    else atomicOr(&a.ctr->overflow, 8u);
+                }
+            }
         }
+        return;                   // the large-primitive work list of the count pass is reused
+    }
+    // large primitives: one work item per 64 tiles of the span.  The wavefront reserves its
+    // items with a single atomic (prefix sum of the lanes' chunk counts), then every lane
+    // writes its own.
+    const uint32_t chunks = (valid && ntiles > BIN_SMALL) ? (uint32_t)(ntiles + WAVE - 1) / WAVE : 0u;
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    const uint32_t wave_total = __shfl(incl, WAVE - 1);
+    if (wave_total == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.ctr->n_work, wave_total);
+    base = __shfl(base, 0) + incl - chunks;
+    for (uint32_t c = 0; c < chunks; ++c) {
+        if (base + c < a.work_cap) a.work[base + c] = make_uint2(u, c);
+        else atomicOr(&a.ctr->overflow, 2u);
     }
 }
 
@@ -155,26 +206,30 @@ k_bin_large(const FrameConst fc, const BinArgs a)
         bool is_quad;
         uint32_t id;
         TileSpan sp;
-        if (!prim_span(fc, a, item.x, n_tris, n_quads, is_quad, id, sp)) continue;
+        PrimBox pb;
+        if (!prim_span(fc, a, item.x, n_tris, n_quads, is_quad, id, pb, sp)) continue;
         const int bw = sp.tx1 - sp.tx0, total = bw * (sp.ty1 - sp.ty0);
         const int j = (int)item.y * WAVE + lane;
         if (j >= total) continue;
         const int tx = sp.tx0 + j % bw, ty = sp.ty0 + j / bw;
-        if (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0)) bin_emit<FILL>(fc, a, is_quad, id, tx, ty);
+        if (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0))
+            bin_emit<FILL>(fc, a, pair_class(fc, is_quad, pb, tx, ty), id, tx, ty);
     }
 }
 
-// Exclusive scan of the 2 * n_tiles bin counts by one workgroup of 1024 threads, 8 coalesced
-// rows of 1024 counts per round; zeroes the counts (the fill pass reuses them as cursors),
-// records the per-class totals and flags overflow of the item array.
+// Exclusive scan of the BIN_CLASSES * n_tiles bin counts by one workgroup of 1024 threads,
+// 24 coalesced rows of 1024 counts per round; zeroes the counts (the fill pass reuses them as
+// cursors), records the per-class totals and flags overflow of the item array.
 __global__ void __launch_bounds__(1024)
 k_scan_bins(uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_offset, int n_tiles,
             uint32_t item_cap, Counters *__restrict__ ctr)
 {
-    constexpr int ROWS = 8, NT = 1024, NW = NT / WAVE;
+    // 24 rows: the 3 x 8 160 bins of a 1920x1080 frame are scanned in a single round, with all
+    // of a thread's loads in flight at once (one workgroup cannot hide latency any other way)
+    constexpr int ROWS = 24, NT = 1024, NW = NT / WAVE;
     __shared__ uint32_t wave_sum[ROWS][NW];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int n = 2 * n_tiles;
+    const int n = BIN_CLASSES * n_tiles;
     uint32_t carry = 0;
     for (int base = 0; base < n; base += ROWS * NT) {
         uint32_t v[ROWS], inc[ROWS];
@@ -217,7 +272,7 @@ k_scan_bins(uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_offset,
     }
     if (tid == 0) {
         bin_offset[n] = carry;
-        const uint32_t tri_total = bin_offset[n_tiles];   // written above by this workgroup
+        const uint32_t tri_total = bin_offset[2 * n_tiles];   // written above by this workgroup
         ctr->tri_bin_total = tri_total;
         ctr->quad_bin_total = carry - tri_total;
         if (carry > item_cap) atomicOr(&ctr->overflow, 1u);
@@ -239,38 +294,97 @@ __device__ __forceinline__ double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// One wavefront per tile, one pixel per lane.
-__global__ void __launch_bounds__(256)
+// Order-preserving key of a non-NaN double: unsigned comparison of keys == comparison of values.
+__device__ __forceinline__ unsigned long long z_key(double z)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(z);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double z_unkey(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// One small (triangle, tile) pair walked by one thread: every sample of the pixel box that
+// lies in the tile.  SWEEP 0: atomicMin/Max of z into the tile's LDS z-buffer.  SWEEP 1: the
+// same samples again; where this face's z is the final z, atomicMax of the face index.
+template <int SWEEP>
+__device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, const TriClip *clips,
+                                           int gx, int gy, bool rh, unsigned long long *s_key, int *s_win,
+                                           unsigned int &frags)
+{
+    const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
+    const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
+    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    for (int py = y0; py < y1; ++py) {
+        for (int px = x0; px < x1; ++px) {
+            float u, v, w;
+            tri_bary(t, (double)px, (double)py, single, u, v, w);
+            if (!(u >= 0 && v >= 0 && w >= 0)) continue;
+            if (SWEEP == 0) ++frags;
+            if (t.flags & TF_CLIP) {
+                const TriClip &c = clips[t.face];
+                double p[3];
+                persp_bary(c.dp, u, v, w, single, p);
+                if (!(inside_clip(p, c.clip) && inside_clip(p, c.clipd))) continue;
+            }
+            const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
+                                       t.zl0, t.zl1, t.zl2);
+            if (z != z) continue;                    // a NaN depth never passes the reference's test
+            const int p = (py - gy) * TILE_W + (px - gx);
+            const unsigned long long k = z_key(z);
+            if (SWEEP == 0) {
+                if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
+            } else if (s_key[p] == k) {
+                atomicMax(&s_win[p], t.face);
+            }
+        }
+    }
+}
+
+// One workgroup per tile, one pixel per thread.  Tiles are dealt to workgroups in plain
+// row-major order, i.e. round-robin over the XCDs: heavy tiles cluster on the screen, and an
+// XCD-contiguous mapping (tried first) left six of the eight XCDs idle behind the two that
+// owned the mesh and its shadow (measured: 330 workgroups resident on average).
+__global__ void __launch_bounds__(TILE_PX)
 k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriClip *__restrict__ clips,
               const QuadRec *__restrict__ quads, const uint32_t *__restrict__ bin_offset,
-              const uint32_t *__restrict__ items, uint32_t item_cap, double *__restrict__ zbuf,
-              int32_t *__restrict__ winner, int16_t *__restrict__ stencil, uint32_t *__restrict__ tile_stats)
+              const uint32_t *__restrict__ items, uint32_t item_cap, uint32_t *__restrict__ bin_count,
+              double *__restrict__ zbuf, int32_t *__restrict__ winner, int32_t *__restrict__ stencil,
+              uint32_t *__restrict__ tile_stats)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int tile = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    __shared__ unsigned long long s_key[TILE_PX];
+    __shared__ int s_win[TILE_PX];
+    __shared__ unsigned int s_cnt[TILE_STATS];
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int n_tiles = fc.tiles_x * fc.tiles_y;
+    const int tile = (int)blockIdx.x;
     if (tile >= n_tiles) return;
-    const int tx = tile % fc.tiles_x, ty = tile / fc.tiles_x + fc.tile_y0;
-    const int px = tx * TILE_W + (lane & (TILE_W - 1));
-    const int py = ty * TILE_H + (lane / TILE_W);
+    const int gx = (tile % fc.tiles_x) * TILE_W, gy = (tile / fc.tiles_x + fc.tile_y0) * TILE_H;
+    const int lp = tid;                                   // pixel of this thread inside the tile
+    const int px = gx + (lp & (TILE_W - 1)), py = gy + lp / TILE_W;
     const bool live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
     const double dpx = (double)px, dpy = (double)py;
     const bool rh = fc.system == 1;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 
+    // list bounds (an overflowing item array is truncated; the host grows it and re-renders)
+    const uint32_t sbeg = min(bin_offset[tile], item_cap), send = min(bin_offset[tile + 1], item_cap);
+    const uint32_t bbeg = min(bin_offset[n_tiles + tile], item_cap), bend = min(bin_offset[n_tiles + tile + 1], item_cap);
+    const uint32_t qbeg = bin_offset[2 * n_tiles + tile], qend = bin_offset[2 * n_tiles + tile + 1];
+    if (tid < TILE_STATS) s_cnt[tid] = 0;
+
+    // ---- big pairs, one pixel per thread (obj/triangular.py:72-118)
     double zbest = rh ? INFINITY : -INFINITY;
     int best = -1;
     unsigned int frags = 0;
-
-    // ---- triangles: coverage, per-fragment clip, depth (obj/triangular.py:72-118)
-    // (an overflowing item array is truncated; the host then grows it and renders the frame again)
-    const uint32_t tbeg = min(bin_offset[tile], item_cap), tend = min(bin_offset[tile + 1], item_cap);
-    for (uint32_t base = tbeg; base < tend; base += WAVE) {
-        const int n = (int)min((uint32_t)WAVE, tend - base);
-        TriRec mine;
-        {
-            const uint32_t id = lane < n ? items[base + lane] : items[base];
-            mine = tris[id];
-        }
+    for (uint32_t base = bbeg; base < bend; base += WAVE) {
+        const int n = (int)min((uint32_t)WAVE, bend - base);
+        const TriRec mine = tris[lane < n ? items[base + lane] : items[base]];
+        const int m_bx = (int)(uint16_t)mine.x0 | ((int)(uint16_t)mine.x1 << 16);
+        const int m_by = (int)(uint16_t)mine.y0 | ((int)(uint16_t)mine.y1 << 16);
         for (int j = 0; j < n; ++j) {
             TriRec t;
             t.ax = bcast(mine.ax, j); t.ay = bcast(mine.ay, j);
@@ -278,8 +392,7 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
             t.v1x = bcast(mine.v1x, j); t.v1y = bcast(mine.v1y, j);
             t.d00 = bcast(mine.d00, j); t.d01 = bcast(mine.d01, j);
             t.d11 = bcast(mine.d11, j); t.inv_den = bcast(mine.inv_den, j);
-            const int bx = bcast((int)(uint16_t)mine.x0 | ((int)(uint16_t)mine.x1 << 16), j);
-            const int by = bcast((int)(uint16_t)mine.y0 | ((int)(uint16_t)mine.y1 << 16), j);
+            const int bx = bcast(m_bx, j), by = bcast(m_by, j);
             const uint32_t flags = (uint32_t)bcast((int)mine.flags, j);
             const int f = bcast(mine.face, j);
             const bool single = (flags & TF_SINGLE_BOX) != 0;
@@ -293,8 +406,8 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
             if (flags & TF_CLIP) {
                 if (in) {
                     const TriClip &c = clips[f];
-                    const double wc = rows_dot3(single, (double)u, (double)v, (double)w, c.dp[0], c.dp[1], c.dp[2]);
-                    double p[3] = { ((double)u * c.dp[0]) / wc, ((double)v * c.dp[1]) / wc, ((double)w * c.dp[2]) / wc };
+                    double p[3];
+                    persp_bary(c.dp, u, v, w, single, p);
                     in = inside_clip(p, c.clip) && inside_clip(p, c.clipd);
                 }
             }
@@ -305,83 +418,146 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
             if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
         }
     }
+    __syncthreads();                                      // s_cnt is zeroed
+    if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
+    s_key[lp] = z_key(zbest);
+    __syncthreads();
 
-    // ---- shadow quads against the final z: stencil +-1 (obj/triangular.py:335-368)
-    int sten = 0;
-    unsigned int qfrags = 0, qupd = 0;
-    if (fc.flags & MR_FRAME_SHADOWS) {
-        const uint32_t qbeg = min(bin_offset[n_tiles + tile], item_cap), qend = min(bin_offset[n_tiles + tile + 1], item_cap);
-        for (uint32_t base = qbeg; base < qend; base += WAVE) {
-            const int n = (int)min((uint32_t)WAVE, qend - base);
-            const uint32_t myid = lane < n ? items[base + lane] : items[base];
-            const QuadRec *mq = quads + myid;
-            const double m_nx = mq->nx, m_ny = mq->ny, m_nz = mq->nz, m_d = mq->d;
-            const int m_bx = (int)(uint16_t)mq->x0 | ((int)(uint16_t)mq->x1 << 16);
-            const int m_by = (int)(uint16_t)mq->y0 | ((int)(uint16_t)mq->y1 << 16);
-            const int m_nf = mq->n | (mq->is_front ? 0x100 : 0);
-            QuadEdge me[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) me[i] = mq->e[i];
-            for (int j = 0; j < n; ++j) {
-                const int bx = bcast(m_bx, j), by = bcast(m_by, j), nf = bcast(m_nf, j);
-                const bool front = (nf & 0x100) != 0;
-                const int nv = nf & 0xff;
-                bool in = live && px >= (bx & 0xffff) && px < (bx >> 16) && py >= (by & 0xffff) && py < (by >> 16);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < 3 || nv > 3) {
-                        const double ax = dpx - bcast(me[i].sx, j), ay = dpy - bcast(me[i].sy, j);
-                        const double cr = ax * bcast(me[i].ey, j) - ay * bcast(me[i].ex, j);
-                        in = in && (front ? cr > 0 : cr < 0);
-                    }
-                }
-                if (nv > 4) {                       // clipped polygons with 5+ vertices are rare
-                    const QuadRec *q = quads + bcast((int)myid, j);
-                    for (int i = 4; i < nv; ++i) {
-                        const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
-                        const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
-                        in = in && (front ? cr > 0 : cr < 0);
-                    }
-                }
-                const unsigned long long m = __ballot(in);
-                if (!m) continue;
-                qfrags += (unsigned int)__popcll(m);
-                double z = -((bcast(m_nx, j) * dpx + bcast(m_ny, j) * dpy) + bcast(m_d, j)) / bcast(m_nz, j);
-                z = linearize_z(fc, z);
-                const bool pass = in && (rh ? (zbest >= z) : (zbest <= z));
-                qupd += (unsigned int)__popcll(__ballot(pass));
-                sten += pass ? (front ? 1 : -1) : 0;
-            }
-        }
+    // ---- small pairs, one triangle per thread, z into the LDS z-buffer
+    unsigned int sfrags = 0;
+    for (uint32_t i = sbeg + tid; i < send; i += TILE_PX) {
+        const TriRec t = tris[items[i]];
+        small_pair<0>(fc, t, clips, gx, gy, rh, s_key, s_win, sfrags);
     }
+    if (sfrags) atomicAdd(&s_cnt[0], sfrags);
+    __syncthreads();
+
+    // ---- winners: big pairs keep their face where their z survived, then the small pairs' sweep
+    const unsigned long long kfinal = s_key[lp];
+    s_win[lp] = (best >= 0 && kfinal == z_key(zbest)) ? best : -1;
+    __syncthreads();
+    for (uint32_t i = sbeg + tid; i < send; i += TILE_PX) {
+        const TriRec t = tris[items[i]];
+        small_pair<1>(fc, t, clips, gx, gy, rh, s_key, s_win, sfrags);
+    }
+    __syncthreads();
+    best = s_win[lp];
+    zbest = z_unkey(kfinal);
 
     if (live) {
         const size_t at = (size_t)py * fc.width + px;
         zbuf[at] = zbest;
         winner[at] = best;
-        stencil[at] = (int16_t)sten;
+        stencil[at] = 0;                                  // k_tile_quads adds the shadow volumes
     }
     const unsigned long long cov = __ballot(live && best >= 0);
-    const unsigned long long litm = __ballot(live && best >= 0 && (int16_t)sten == 0);
-    // per-tile partial counts, summed by k_reduce_tile_stats (32 400 wavefronts adding to one
-    // cache line of counters would serialise at the memory side)
-    if (lane == 0) {
-        uint32_t *o = tile_stats + (size_t)tile * TILE_STATS;
-        o[0] = frags; o[1] = qfrags; o[2] = qupd;
-        o[3] = (uint32_t)__popcll(cov); o[4] = (uint32_t)__popcll(litm);
+    if (lane == 0 && cov) atomicAdd(&s_cnt[3], (unsigned int)__popcll(cov));
+    __syncthreads();
+    // per-tile partial counts, summed by k_reduce_tile_stats (thousands of workgroups adding to
+    // one cache line of counters would serialise at the memory side)
+    if (tid < TILE_STATS) tile_stats[(size_t)tile * TILE_REC + tid] = s_cnt[tid];
+    if (tid == 0) {                                       // diagnostics for mr_debug_read_tile_records
+        uint32_t *o = tile_stats + (size_t)tile * TILE_REC;
+        o[5] = (uint32_t)t_start;
+        o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        o[7] = min(send - sbeg, 0xfffu) | (min(bend - bbeg, 0x3ffu) << 12) | (min(qend - qbeg, 0x3ffu) << 22);
+    }
+    if (tid < BIN_CLASSES) bin_count[tid * n_tiles + tile] = 0;   // bin cursors zeroed for the next frame
+}
+
+// Shadow quads against the final z: stencil +-1 (obj/triangular.py:335-368).  One workgroup
+// per work item (tile, <= QUAD_BATCH quads), one pixel per thread; the item's records are
+// staged in registers and broadcast.  The stencil lives in a 32-bit buffer that k_tile_raster
+// zeroed; items of one tile add into it with coalesced atomics (adds commute, so the order of
+// the quads never mattered: obj/triangular.py:365-368).
+__global__ void __launch_bounds__(TILE_PX)
+k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4 *__restrict__ quad_work,
+             uint32_t quad_work_cap, const uint32_t *__restrict__ items, uint32_t item_cap,
+             const double *__restrict__ zbuf, int32_t *__restrict__ stencil, uint32_t *__restrict__ tile_stats,
+             const Counters *__restrict__ ctr)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const uint32_t n_work = min(ctr->n_quad_work, quad_work_cap);
+    const bool rh = fc.system == 1;
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint4 item = quad_work[wi];
+        const int tile = (int)item.x;
+        const uint32_t base = item.y;
+        const int n = (int)min(item.z, item_cap > base ? item_cap - base : 0u);
+        const int gx = (tile % fc.tiles_x) * TILE_W, gy = (tile / fc.tiles_x + fc.tile_y0) * TILE_H;
+        const int px = gx + (tid & (TILE_W - 1)), py = gy + tid / TILE_W;
+        const bool live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
+        const double dpx = (double)px, dpy = (double)py;
+        const size_t at = (size_t)py * fc.width + px;
+        const double zbest = live ? zbuf[at] : 0.0;
+
+        const uint32_t myid = n > 0 ? items[base + min(lane, n - 1)] : 0u;
+        const QuadRec *mq = quads + myid;
+        const double m_nx = mq->nx, m_ny = mq->ny, m_nz = mq->nz, m_d = mq->d;
+        const int m_bx = (int)(uint16_t)mq->x0 | ((int)(uint16_t)mq->x1 << 16);
+        const int m_by = (int)(uint16_t)mq->y0 | ((int)(uint16_t)mq->y1 << 16);
+        const int m_nf = mq->n | (mq->is_front ? 0x100 : 0);
+        QuadEdge me[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) me[i] = mq->e[i];
+
+        int sten = 0;
+        unsigned int qfrags = 0, qupd = 0;
+        for (int j = 0; j < n; ++j) {
+            const int bx = bcast(m_bx, j), by = bcast(m_by, j), nf = bcast(m_nf, j);
+            const bool front = (nf & 0x100) != 0;
+            const int nv = nf & 0xff;
+            bool in = live && px >= (bx & 0xffff) && px < (bx >> 16) && py >= (by & 0xffff) && py < (by >> 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < 3 || nv > 3) {
+                    const double ax = dpx - bcast(me[i].sx, j), ay = dpy - bcast(me[i].sy, j);
+                    const double cr = ax * bcast(me[i].ey, j) - ay * bcast(me[i].ex, j);
+                    in = in && (front ? cr > 0 : cr < 0);
+                }
+            }
+            if (nv > 4) {                           // clipped polygons with 5+ vertices are rare
+                const QuadRec *q = quads + bcast((int)myid, j);
+                for (int i = 4; i < nv; ++i) {
+                    const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
+                    const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
+                    in = in && (front ? cr > 0 : cr < 0);
+                }
+            }
+            const unsigned long long m = __ballot(in);
+            if (!m) continue;
+            qfrags += (unsigned int)__popcll(m);
+            double z = -((bcast(m_nx, j) * dpx + bcast(m_ny, j) * dpy) + bcast(m_d, j)) / bcast(m_nz, j);
+            z = linearize_z(fc, z);
+            const bool pass = in && (rh ? (zbest >= z) : (zbest <= z));
+            qupd += (unsigned int)__popcll(__ballot(pass));
+            sten += pass ? (front ? 1 : -1) : 0;
+        }
+        if (sten) atomicAdd(&stencil[at], sten);
+        if (lane == 0) {
+            if (qfrags) atomicAdd(&tile_stats[(size_t)tile * TILE_REC + 1], qfrags);
+            if (qupd) atomicAdd(&tile_stats[(size_t)tile * TILE_REC + 2], qupd);
+        }
     }
 }
 
-// Sums the per-tile partial counts into the frame counters (one workgroup).
+// Sums the per-tile partial counts into the frame counters and counts the lit pixels (covered
+// and stencil == 0, compared as int16 like the reference's buffer); one workgroup, run only
+// when the statistics are asked for.
 __global__ void __launch_bounds__(1024)
-k_reduce_tile_stats(const uint32_t *__restrict__ tile_stats, int n_tiles, Counters *__restrict__ ctr)
+k_reduce_tile_stats(const FrameConst fc, const uint32_t *__restrict__ tile_stats, int n_tiles,
+                    const int32_t *__restrict__ winner, const int32_t *__restrict__ stencil,
+                    Counters *__restrict__ ctr)
 {
     __shared__ unsigned long long part[TILE_STATS][1024 / WAVE];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     unsigned long long acc[TILE_STATS] = {};
     for (int t = tid; t < n_tiles; t += blockDim.x)
 #pragma unroll
-        for (int k = 0; k < TILE_STATS; ++k) acc[k] += tile_stats[(size_t)t * TILE_STATS + k];
+        for (int k = 0; k < TILE_STATS - 1; ++k) acc[k] += tile_stats[(size_t)t * TILE_REC + k];
+    const size_t p0 = (size_t)fc.band_y0 * fc.width, p1 = (size_t)fc.band_y1 * fc.width;
+    for (size_t p = p0 + tid; p < p1; p += blockDim.x)
+        acc[4] += (winner[p] >= 0 && (int16_t)stencil[p] == 0) ? 1u : 0u;
 #pragma unroll
     for (int k = 0; k < TILE_STATS; ++k) {
         unsigned long long v = acc[k];

@@ -23,7 +23,7 @@ struct ShadeArgs {
     const Material *materials;
     const Texture *textures;
     const int32_t *winner;
-    const int16_t *stencil;
+    const int32_t *stencil;    // 32-bit accumulator; the reference's buffer is its low 16 bits
     float *frame;          // optional float frame (row = screen y), may be null
     uint8_t *out;          // band of the final frame, row 0 = top row of the band
 };
@@ -114,7 +114,7 @@ k_shade(const FrameConst fc, const ShadeArgs a)
     float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
     const int f = a.winner[at];
     if (f >= 0) {
-        const bool lit = a.stencil[at] == 0;
+        const bool lit = (int16_t)a.stencil[at] == 0;
         const TriRec t = a.tris[f];
         const int32_t *fcx = a.faces + (size_t)f * 12;
         const int vi[3] = { fcx[0], fcx[4], fcx[8] };

@@ -90,9 +90,9 @@ struct mr_scene {
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
     // ---- per-frame work buffers
     DevBuf d_vout, d_tris, d_clips, d_status, d_lit, d_valid, d_quads, d_sil, d_counters;
-    DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_tile_stats;
+    DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_quad_work, d_tile_stats;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
-    uint32_t item_cap = 0, work_cap = 0, quad_cap = 0;
+    uint32_t item_cap = 0, work_cap = 0, quad_cap = 0, quad_work_cap = 0;
 
     mr::Counters *h_counters = nullptr;      // pinned
     // Event marks of the last EVENT_RING frames (frames are enqueued without host syncs, so a
@@ -106,7 +106,8 @@ struct mr_scene {
     bool events_ok = false;
 
     mr_frame_desc last_frame = {};
-    bool have_frame = false;
+    int last_n_tiles = 0, bins_zeroed_for = 0;
+    bool have_frame = false, stats_reduced = false;
     mr_stats stats = {};
     int n_silhouette = 0;
 };
@@ -242,6 +243,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     if (sc->quad_cap == 0) sc->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
     if (sc->item_cap == 0) sc->item_cap = (uint32_t)std::max<size_t>(4 * nF + 8 * (size_t)n_tiles, 1u << 22);
     if (sc->work_cap == 0) sc->work_cap = 1u << 18;
+    if (sc->quad_work_cap == 0) sc->quad_work_cap = (uint32_t)n_tiles + (1u << 16);
 
     HIP_TRY(sc->d_vout.ensure(nV * sizeof(VertexOut)));
     HIP_TRY(sc->d_tris.ensure(nF * sizeof(TriRec)));
@@ -252,14 +254,15 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     HIP_TRY(sc->d_quads.ensure((size_t)sc->quad_cap * sizeof(QuadRec)));
     HIP_TRY(sc->d_sil.ensure((size_t)sc->quad_cap * 3 * sizeof(int32_t)));
     HIP_TRY(sc->d_counters.ensure(sizeof(Counters)));
-    HIP_TRY(sc->d_bin_count.ensure((size_t)(2 * n_tiles + 1) * 4));
-    HIP_TRY(sc->d_bin_offset.ensure((size_t)(2 * n_tiles + 1) * 4));
+    HIP_TRY(sc->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
+    HIP_TRY(sc->d_bin_offset.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
     HIP_TRY(sc->d_items.ensure((size_t)sc->item_cap * 4));
     HIP_TRY(sc->d_work.ensure((size_t)sc->work_cap * sizeof(uint2)));
-    HIP_TRY(sc->d_tile_stats.ensure((size_t)n_tiles * TILE_STATS * 4));
+    HIP_TRY(sc->d_quad_work.ensure((size_t)sc->quad_work_cap * sizeof(uint4)));
+    HIP_TRY(sc->d_tile_stats.ensure((size_t)n_tiles * TILE_REC * 4));
     HIP_TRY(sc->d_z.ensure(npx * sizeof(double)));
     HIP_TRY(sc->d_winner.ensure(npx * sizeof(int32_t)));
-    HIP_TRY(sc->d_stencil.ensure(npx * sizeof(int16_t)));
+    HIP_TRY(sc->d_stencil.ensure(npx * sizeof(int32_t)));
     if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(sc->d_frame.ensure(npx * 3 * sizeof(float)));
     if (!sc->events_ok) {
         for (auto &set : sc->ev_ring) for (auto &e : set) HIP_TRY(hipEventCreate(&e));
@@ -270,20 +273,23 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
 
     Counters *ctr = sc->d_counters.as<Counters>();
     HIP_TRY(hipEventRecord(sc->ev[0], stream));
-    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_bin_count.p, 0, (size_t)(2 * n_tiles + 1) * 4, stream));
+    // The bin cursors are left zeroed by k_tile_raster and the frame counters are cleared by
+    // k_vertex, so a steady-state frame issues no memset; only a new tile grid needs one.
+    if (sc->bins_zeroed_for != BIN_CLASSES * n_tiles + 1) {
+        HIP_TRY(hipMemsetAsync(sc->d_bin_count.p, 0, sc->d_bin_count.cap, stream));
+        sc->bins_zeroed_for = BIN_CLASSES * n_tiles + 1;
+    }
 
     // ---- geometry
-    if (fc.n_vertices > 0)
-        hipLaunchKernelGGL(k_vertex, dim3(blocks_for(fc.n_vertices, 256)), dim3(256), 0, stream, fc,
-                           sc->d_verts.as<double>(), sc->d_vout.as<VertexOut>());
+    hipLaunchKernelGGL(k_vertex, dim3(blocks_for(fc.n_vertices, 256)), dim3(256), 0, stream, fc,
+                       sc->d_verts.as<double>(), sc->d_vout.as<VertexOut>(), ctr);
     if (fc.n_faces > 0) {
         hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
                            sc->d_vout.as<VertexOut>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
                            sc->d_status.as<uint8_t>(), sc->d_lit.as<uint8_t>(), sc->d_valid.as<uint32_t>(), ctr);
         HIP_TRY(hipEventRecord(sc->ev[1], stream));
-        hipLaunchKernelGGL(k_tri_count, dim3(blocks_for((long long)fc.n_faces * WAVE, 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(k_tri_count, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream,
                            fc, sc->d_valid.as<uint32_t>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
                            sc->d_status.as<uint8_t>(), ctr);
     } else {
@@ -305,8 +311,9 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     ba.bin_count = sc->d_bin_count.as<uint32_t>(); ba.bin_offset = sc->d_bin_offset.as<uint32_t>();
     ba.items = sc->d_items.as<uint32_t>(); ba.item_cap = sc->item_cap;
     ba.work = sc->d_work.as<uint2>(); ba.work_cap = sc->work_cap;
+    ba.quad_work = sc->d_quad_work.as<uint4>(); ba.quad_work_cap = sc->quad_work_cap;
     const long long n_prims_max = (long long)fc.n_faces + (shadows ? std::min<long long>(fc.n_edges, sc->quad_cap) : 0);
-    const unsigned classify_blocks = blocks_for(n_prims_max, 256);
+    const unsigned classify_blocks = blocks_for(std::max<long long>(n_prims_max, n_tiles), 256);
     const unsigned large_blocks = 1024;      // grid-stride over the work items, 4 wavefronts per block
     hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
     hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
@@ -318,12 +325,16 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     HIP_TRY(hipEventRecord(sc->ev[5], stream));
 
     // ---- visibility: coverage, z, stencil
-    hipLaunchKernelGGL(k_tile_raster, dim3(blocks_for(n_tiles, 256 / WAVE)), dim3(256), 0, stream, fc,
+    const unsigned raster_blocks = (unsigned)n_tiles;
+    hipLaunchKernelGGL(k_tile_raster, dim3(raster_blocks), dim3(TILE_PX), 0, stream, fc,
                        sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(), sc->d_quads.as<QuadRec>(),
                        sc->d_bin_offset.as<uint32_t>(), sc->d_items.as<uint32_t>(), sc->item_cap,
-                       sc->d_z.as<double>(), sc->d_winner.as<int32_t>(), sc->d_stencil.as<int16_t>(),
-                       sc->d_tile_stats.as<uint32_t>());
-    hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, stream, sc->d_tile_stats.as<uint32_t>(), n_tiles, ctr);
+                       sc->d_bin_count.as<uint32_t>(), sc->d_z.as<double>(), sc->d_winner.as<int32_t>(),
+                       sc->d_stencil.as<int32_t>(), sc->d_tile_stats.as<uint32_t>());
+    if (shadows)
+        hipLaunchKernelGGL(k_tile_quads, dim3(2048), dim3(TILE_PX), 0, stream, fc, sc->d_quads.as<QuadRec>(),
+                           sc->d_quad_work.as<uint4>(), sc->quad_work_cap, sc->d_items.as<uint32_t>(), sc->item_cap,
+                           sc->d_z.as<double>(), sc->d_stencil.as<int32_t>(), sc->d_tile_stats.as<uint32_t>(), ctr);
     HIP_TRY(hipEventRecord(sc->ev[6], stream));
 
     // ---- deferred shading + finalise
@@ -332,17 +343,34 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     sa.face_flags = sc->d_face_flags.as<uint8_t>(); sa.verts = sc->d_verts.as<double>();
     sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
     sa.materials = sc->d_materials.as<Material>(); sa.textures = sc->d_textures.as<Texture>();
-    sa.winner = sc->d_winner.as<int32_t>(); sa.stencil = sc->d_stencil.as<int16_t>();
+    sa.winner = sc->d_winner.as<int32_t>(); sa.stencil = sc->d_stencil.as<int32_t>();
     sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? sc->d_frame.as<float>() : nullptr;
     sa.out = d_out;
     const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(band_px, 256)), dim3(256), 0, stream, fc, sa);
     HIP_TRY(hipEventRecord(sc->ev[7], stream));
-    HIP_TRY(hipMemcpyAsync(sc->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipGetLastError());
     sc->last_frame = *fr;
+    sc->last_n_tiles = n_tiles;
     sc->have_frame = true;
+    sc->stats_reduced = false;
     sc->frames_enqueued += 1;
+    return MR_OK;
+}
+
+// The fragment / pixel counts of a frame are left as per-tile partials by k_tile_raster; they
+// are summed and fetched only when somebody asks (mr_render, mr_get_stats), not per frame.
+int fetch_counters(mr_scene *sc, hipStream_t stream)
+{
+    using namespace mr;
+    Counters *ctr = sc->d_counters.as<Counters>();
+    if (!sc->stats_reduced) {
+        const FrameConst fc = make_const(sc, &sc->last_frame);
+        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, stream, fc, sc->d_tile_stats.as<uint32_t>(),
+                           sc->last_n_tiles, sc->d_winner.as<int32_t>(), sc->d_stencil.as<int32_t>(), ctr);
+        sc->stats_reduced = true;
+    }
+    HIP_TRY(hipMemcpyAsync(sc->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
     return MR_OK;
 }
 
@@ -368,6 +396,7 @@ int collect(mr_scene *sc, bool with_copy)
         const uint32_t entries = c.tri_bin_total + c.quad_bin_total;
         if (c.overflow & 1u) { sc->item_cap = entries + entries / 2 + 1024; }
         if (c.overflow & 2u) { sc->work_cap = c.n_work + c.n_work / 2 + 1024; }
+        if (c.overflow & 8u) { sc->quad_work_cap = c.n_quad_work + c.n_quad_work / 2 + 1024; }
         if (c.overflow & 4u) { sc->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, sc->quad_cap * 2); }
         if (c.n_quads > sc->quad_cap) sc->quad_cap = c.n_quads + c.n_quads / 2 + 64;
         return MR_E_OVERFLOW;
@@ -427,8 +456,8 @@ int mr_scene_clear(mr_scene *sc)
     sc->texture_allocs.clear(); sc->textures.clear();
     sc->verts.clear(); sc->uv.clear(); sc->normals.clear(); sc->faces.clear(); sc->face_flags.clear();
     sc->materials.clear(); sc->models.clear(); sc->edge_offset.clear(); sc->edge_inc.clear();
-    sc->dirty = true; sc->have_frame = false;
-    sc->item_cap = sc->work_cap = sc->quad_cap = 0;
+    sc->dirty = true; sc->have_frame = false; sc->bins_zeroed_for = 0;
+    sc->item_cap = sc->work_cap = sc->quad_cap = sc->quad_work_cap = 0;
     return MR_OK;
 }
 
@@ -440,7 +469,7 @@ void mr_scene_destroy(mr_scene *sc)
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
                        &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_vout, &sc->d_tris, &sc->d_clips,
                        &sc->d_status, &sc->d_lit, &sc->d_valid, &sc->d_quads, &sc->d_sil, &sc->d_counters,
-                       &sc->d_bin_count, &sc->d_bin_offset, &sc->d_items, &sc->d_work, &sc->d_tile_stats, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
+                       &sc->d_bin_count, &sc->d_bin_offset, &sc->d_items, &sc->d_work, &sc->d_quad_work, &sc->d_tile_stats, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
     for (DevBuf *b : bufs) b->release();
     if (sc->events_ok) {
         for (auto &set : sc->ev_ring) for (auto &e : set) (void)hipEventDestroy(e);
@@ -521,7 +550,7 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
     sc->face_flags.insert(sc->face_flags.end(), (size_t)m->n_faces, ff);
     sc->models.push_back(mi);
     sc->dirty = true;
-    sc->item_cap = sc->work_cap = sc->quad_cap = 0;
+    sc->item_cap = sc->work_cap = sc->quad_cap = sc->quad_work_cap = 0;
     return (int)sc->models.size() - 1;
 }
 
@@ -535,6 +564,7 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     for (int attempt = 0; attempt < 6; ++attempt) {
         HIP_TRY(sc->d_out.ensure(band_bytes));
         if ((rc = enqueue_frame(sc, fr, sc->d_out.as<uint8_t>(), g_stream))) return rc;
+        if ((rc = fetch_counters(sc, g_stream))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipEventRecord(sc->ev[8], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
@@ -562,7 +592,10 @@ int mr_get_stats(mr_scene *sc, mr_stats *stats)
     if (!sc || !stats) return fail(MR_E_INVALID, "NULL argument");
     if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
     HIP_TRY(hipDeviceSynchronize());
-    int rc = collect(sc, false);
+    int rc = fetch_counters(sc, g_stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    rc = collect(sc, false);
     *stats = sc->stats;
     if (rc == MR_E_OVERFLOW)
         return fail(MR_E_OVERFLOW, "the last frame overflowed a work list (now grown): render it again");
@@ -599,7 +632,12 @@ int mr_read_z(mr_scene *sc, double *out)
 int mr_read_stencil(mr_scene *sc, int16_t *out)
 {
     if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    return read_back(sc, sc->d_stencil, out, (size_t)sc->last_frame.width * sc->last_frame.height, "stencil");
+    const size_t n = (size_t)sc->last_frame.width * sc->last_frame.height;
+    std::vector<int32_t> wide(n);           // the device accumulates in 32 bits; the reference's buffer is int16
+    int rc = read_back(sc, sc->d_stencil, wide.data(), n, "stencil");
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) out[i] = (int16_t)wide[i];
+    return MR_OK;
 }
 int mr_read_winner(mr_scene *sc, int32_t *out)
 {
@@ -618,6 +656,16 @@ int mr_read_face_status(mr_scene *sc, uint8_t *out)
     if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
     return fail(MR_E_UNSUPPORTED, "per-face status of the lit pass is not implemented yet");
     (void)out;
+}
+
+int mr_debug_read_tile_records(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
+{
+    if (!sc || !out) return fail(MR_E_INVALID, "NULL argument");
+    if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    const int n = std::min(sc->last_n_tiles, cap_tiles);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, sc->d_tile_stats.p, (size_t)n * mr::TILE_REC * 4, hipMemcpyDeviceToHost));
+    return sc->last_n_tiles;
 }
 
 int mr_read_silhouette(mr_scene *sc, int32_t *out, int32_t cap)

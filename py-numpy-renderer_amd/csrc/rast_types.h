@@ -2,17 +2,21 @@
 //
 // Vocabulary follows the reference renderer: faces (triangles), silhouette edges, shadow
 // quads, fragments, z / stencil / frame buffers.  A "tile" is the block of TILE_W x TILE_H
-// pixels owned by one 64-lane wavefront in the visibility kernel.
+// pixels owned by one workgroup of the visibility kernel, which keeps the tile's z-buffer in LDS.
 #pragma once
 
 #include <stdint.h>
 
 namespace mr {
 
-constexpr int TILE_W = 8;
-constexpr int TILE_H = 8;
+constexpr int TILE_W = 16;
+constexpr int TILE_H = 16;
+constexpr int TILE_PX = TILE_W * TILE_H;    // one thread per pixel in the visibility kernel
 constexpr int WAVE = 64;
-static_assert(TILE_W * TILE_H == WAVE, "one pixel per lane");
+// A (triangle, tile) pair whose pixel box inside the tile holds more samples than this is
+// evaluated one pixel per thread ("big" pair); smaller ones one triangle per thread.
+constexpr int BIG_PAIR_PX = 24;
+constexpr int BIN_CLASSES = 3;              // small triangle pairs, big triangle pairs, shadow quads
 
 constexpr int MAX_POLY = 12;   // a quad clipped by six planes has at most 4 + 6 vertices
 
@@ -61,6 +65,8 @@ struct VertexOut {
     double clip[4];              // v @ camera.MVP
     double clipd[4];             // v @ debug_camera.MVP
     double zlin;                 // linearize_z(sz)
+    int32_t safe;                // strictly inside both clip volumes with margin (see k_vertex)
+    int32_t pad;
 };
 
 // Triangle set-up record walked by the visibility kernel: the per-face constants of
@@ -118,7 +124,9 @@ struct Counters {
     unsigned int n_valid_tris, n_quads, n_quads_drawn;
     unsigned int tri_bin_total, quad_bin_total;
     unsigned int n_work;         // (large primitive, 64-tile chunk) work items of the binning pass
-    unsigned int overflow;       // bit0: bin items, bit1: binning work list, bit2: quad list
+    unsigned int n_quad_work;    // (tile, quad batch) work items of the stencil pass
+    unsigned int overflow;       // bit0: bin items, bit1: binning work list, bit2: quad list, bit3: quad work list
+    unsigned int pad;
 };
 
 }  // namespace mr

@@ -1,0 +1,13 @@
+"""Render a scene N times through mr_render (for rocprofv3 runs)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import scenes
+name = sys.argv[1] if len(sys.argv) > 1 else "c4_torus200k_1080p"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+api = scenes.product_api()
+sc = scenes.build(api, name)
+be = sc._backend()
+for _ in range(n):
+    be.render(sc, shadows=True)
+print(be.last_stats)
