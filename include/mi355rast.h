@@ -73,7 +73,8 @@ typedef struct mr_frame_desc {
     double att_constant, att_linear, att_quadratic;
     double spot_edge0, spot_edge1;  /* cos(20 deg), cos(10 deg) (obj/triangular.py:158-159) */
     float background[3];            /* obj/core.py:597-600 */
-    int32_t reserved;
+    uint32_t background_u8;         /* the same colour after obj/core.py:640's finalise, computed by the host:
+                                       r | g << 8 | b << 16 | 1 << 24; 0 = let the device compute it */
 } mr_frame_desc;
 
 /* One material group of a model (obj/materials.py:47-55; obj/core.py:125). */

@@ -31,7 +31,7 @@ class FrameDesc(C.Structure):
                 ("light_color", C.c_double * 3), ("light_ambient", C.c_double * 3),
                 ("specular_strength", C.c_double), ("att_constant", C.c_double), ("att_linear", C.c_double),
                 ("att_quadratic", C.c_double), ("spot_edge0", C.c_double), ("spot_edge1", C.c_double),
-                ("background", C.c_float * 3), ("reserved", C.c_int32)]
+                ("background", C.c_float * 3), ("background_u8", C.c_uint32)]
 
 
 class MaterialDesc(C.Structure):
@@ -126,6 +126,9 @@ def fill_frame_desc(pf, row_band=None, keep_float=False):
     d.spot_edge0, d.spot_edge1 = pf.spot_edge0, pf.spot_edge1
     for i in range(3):
         d.background[i] = float(pf.background[i])
+    # the finalised background exactly as the reference computes it (float32 ** 0.8 * 255 -> uint8)
+    bg = (np.asarray(pf.background, dtype=np.float32) ** 0.8 * 255).astype(np.uint8)
+    d.background_u8 = int(bg[0]) | int(bg[1]) << 8 | int(bg[2]) << 16 | 1 << 24
     return d
 
 

@@ -248,11 +248,19 @@ __device__ int clip_polygon(const double *planes, double (*poly)[4], int n)
     double tmp[MAX_POLY][4];
     for (int pl = 0; pl < 6 && n > 0; ++pl) {
         const double *P = planes + pl * 4;
+        // A plane that has every vertex on its visible side leaves the polygon untouched (the
+        // walk below would copy it verbatim), so it is skipped; a shadow quad is typically cut
+        // by the far plane only.
+        bool vis[MAX_POLY];
+        bool all = true;
+        for (int i = 0; i < n; ++i) { vis[i] = plane_dot(P, poly[i]) >= 0; all = all && vis[i]; }
+        if (all) continue;
         int m = 0;
         for (int i = 0; i < n; ++i) {
+            const int i1 = (i + 1 == n) ? 0 : i + 1;
             const double *cur = poly[i];
-            const double *nxt = poly[(i + 1 == n) ? 0 : i + 1];
-            const bool cv = plane_dot(P, cur) >= 0, nv = plane_dot(P, nxt) >= 0;
+            const double *nxt = poly[i1];
+            const bool cv = vis[i], nv = vis[i1];
             if (cv && m < MAX_POLY) {
                 for (int j = 0; j < 4; ++j) tmp[m][j] = cur[j];
                 ++m;
@@ -280,11 +288,10 @@ __device__ int clip_polygon(const double *planes, double (*poly)[4], int n)
 // One thread per unique undirected edge of the scene.  An edge is on the silhouette when an
 // odd number of its incident light-facing faces toggled it; it keeps the orientation of the
 // last such face in face order (set add/discard semantics of obj/triangular.py:294-302).
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 k_silhouette(const FrameConst fc, const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
-             const int32_t *__restrict__ faces, const uint8_t *__restrict__ lit, const double *__restrict__ verts,
-             QuadRec *__restrict__ quads, int32_t *__restrict__ sil_edges, uint32_t quad_cap,
-             Counters *__restrict__ ctr)
+             const int32_t *__restrict__ faces, const uint8_t *__restrict__ lit,
+             int32_t *__restrict__ sil_edges, uint32_t quad_cap, Counters *__restrict__ ctr)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= fc.n_edges) return;
@@ -303,6 +310,19 @@ k_silhouette(const FrameConst fc, const uint32_t *__restrict__ edge_offset, cons
         sil_edges[sslot * 3 + 1] = ia;
         sil_edges[sslot * 3 + 2] = ib;
     }
+}
+
+// One thread per silhouette edge: extrusion away from the light, clipping against the
+// camera frustum, projection, plane equation and pixel box of the shadow quad
+// (obj/core.py:610-622, obj/plane_intersection.py:59-86, obj/triangular.py:320-340).
+__global__ void __launch_bounds__(64)
+k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const double *__restrict__ verts,
+             QuadRec *__restrict__ quads, uint32_t quad_cap, Counters *__restrict__ ctr)
+{
+    const uint32_t s_idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s_idx >= min(ctr->n_quads, quad_cap)) return;
+    const int e = (int)s_idx;
+    const int ia = sil_edges[s_idx * 3 + 1], ib = sil_edges[s_idx * 3 + 2];
 
     // extrusion (obj/core.py:612-621): quad = (A, B, D, C)
     const double *A = verts + (size_t)ia * 4, *B = verts + (size_t)ib * 4;

@@ -134,6 +134,32 @@ __device__ __forceinline__ void bin_emit(const FrameConst &fc, const BinArgs &a,
     }
 }
 
+// The same for a whole wavefront at once (every lane calls it, `want` says whether it has a
+// pair to emit).  Neighbouring triangles of a mesh fall into the same tile, and a tile's
+// counter is one L2 location: lanes with the same bin are combined into ONE atomic and share
+// out the returned range by rank, instead of queueing up to 64 deep on that location.
+template <bool FILL>
+__device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArgs &a, bool want, int cls,
+                                              uint32_t id, int tx, int ty)
+{
+    const uint32_t bin = (uint32_t)cls * (uint32_t)(fc.tiles_x * fc.tiles_y) + (uint32_t)ty * fc.tiles_x + tx;
+    const int lane = threadIdx.x & (WAVE - 1);
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lbin = (uint32_t)__shfl((int)bin, leader);
+        const unsigned long long same = __ballot(want && bin == lbin) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&a.bin_count[lbin], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (FILL && ((same >> lane) & 1ull)) {
+            const uint32_t at = a.bin_offset[lbin] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (at < a.item_cap) a.items[at] = id;
+        }
+        todo &= ~same;
+    }
+}
+
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_bin_classify(const FrameConst fc, const BinArgs a)
@@ -147,11 +173,19 @@ k_bin_classify(const FrameConst fc, const BinArgs a)
     PrimBox pb = { 0, 0, 0, 0 };
     const bool valid = prim_span(fc, a, u, n_tris, n_quads, is_quad, id, pb, sp);
     const int ntiles = valid ? (sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0) : 0;
-    if (valid && ntiles <= BIN_SMALL) {
-        for (int ty = sp.ty0; ty < sp.ty1; ++ty)
-            for (int tx = sp.tx0; tx < sp.tx1; ++tx)
-                if (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0))
-                    bin_emit<FILL>(fc, a, pair_class(fc, is_quad, pb, tx, ty), id, tx, ty);
+    // small primitives: up to BIN_SMALL (tile) pairs per lane, emitted one "slot" at a time so
+    // that the wavefront can combine lanes that hit the same bin
+    const bool small = valid && ntiles <= BIN_SMALL;
+    if (__ballot(small)) {
+        const int bw = max(sp.tx1 - sp.tx0, 1);
+#pragma unroll
+        for (int slot = 0; slot < BIN_SMALL; ++slot) {
+            const bool has = small && slot < ntiles;
+            const int tx = sp.tx0 + slot % bw, ty = sp.ty0 + slot / bw;
+            const bool want = has && (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0));
+            if (!__ballot(has)) break;
+            bin_emit_wave<FILL>(fc, a, want, want ? pair_class(fc, is_quad, pb, tx, ty) : 0, id, tx, ty);
+        }
     }
     if (FILL) {
         // (fill pass: the offsets exist now) thread u also cuts tile u's shadow-quad list into

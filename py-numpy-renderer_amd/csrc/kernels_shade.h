@@ -47,6 +47,31 @@ __device__ __forceinline__ const float *texel(const Texture &tx, const float *uv
     return tx.rgb + ((size_t)row * tx.w + col) * 3;
 }
 
+// ---- colour-path arithmetic.  Coverage, z and texel indices above are bit-exact; the colour
+// that follows only has to land within +-1 uint8 of the reference (it already differs from it
+// in pow()), so its divisions and square roots use the hardware seeds (v_rcp_f64 / v_rsq_f64,
+// ~2^-23) refined by two Newton steps to ~1e-16 instead of the ~35-instruction IEEE
+// expansions: a lit pixel does some 30 divisions and 7 square roots.
+__device__ __forceinline__ double c_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double c_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    return fma(0.5 * r, fma(-x * r, r, 1.0), r);
+}
+// normalize() of obj/transformation.py:46-49 (zero vectors stay zero)
+__device__ __forceinline__ void c_normalize3(const double a[3], double o[3])
+{
+    const double l2 = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    const double r = l2 > 0 ? c_rsqrt(l2) : 1.0;
+    o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
+}
+
 // 3x3 inverse by LU with partial pivoting (np.linalg.inv -> LAPACK gesv)
 __device__ bool inv3(const double a[3][3], double inv[3][3])
 {
@@ -64,12 +89,13 @@ __device__ bool inv3(const double a[3][3], double inv[3][3])
             for (int j = 0; j < 3; ++j) { double t = lu[col][j]; lu[col][j] = lu[piv][j]; lu[piv][j] = t; }
             int t = perm[col]; perm[col] = perm[piv]; perm[piv] = t;
         }
-        const double r = 1.0 / lu[col][col];
+        const double r = c_rcp(lu[col][col]);
         for (int i = col + 1; i < 3; ++i) {
             lu[i][col] *= r;
             for (int j = col + 1; j < 3; ++j) lu[i][j] = fma(-lu[i][col], lu[col][j], lu[i][j]);
         }
     }
+    const double rd[3] = { c_rcp(lu[0][0]), c_rcp(lu[1][1]), c_rcp(lu[2][2]) };
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         double y[3];
@@ -81,20 +107,26 @@ __device__ bool inv3(const double a[3][3], double inv[3][3])
         for (int i = 2; i >= 0; --i) {
             double s = y[i];
             for (int k = i + 1; k < 3; ++k) s = fma(-lu[i][k], inv[k][j], s);
-            inv[i][j] = s / lu[i][i];
+            inv[i][j] = s * rd[i];
         }
     }
     return true;
 }
 
-// ndarray ** scalar: NumPy's scalar-exponent fast paths, else pow()
+// ndarray ** scalar: NumPy's scalar-exponent fast paths; small whole exponents (the default
+// Ns = 64) by repeated squaring; else pow()
 __device__ __forceinline__ double np_power(double x, double e)
 {
     if (e == 2.0) return x * x;
     if (e == 1.0) return x;
-    if (e == 0.5) return sqrt(x);
+    if (e == 0.5) return x > 0 ? x * c_rsqrt(x) : 0.0;
     if (e == 0.0) return 1.0;
-    if (e == -1.0) return 1.0 / x;
+    if (e == -1.0) return c_rcp(x);
+    if (e > 0 && e <= 1024.0 && e == floor(e)) {
+        double r = 1.0, b = x;
+        for (int k = (int)e; k; k >>= 1) { if (k & 1) r *= b; b *= b; }
+        return r;
+    }
     return pow(x, e);
 }
 
@@ -113,6 +145,13 @@ k_shade(const FrameConst fc, const ShadeArgs a)
 
     float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
     const int f = a.winner[at];
+    if (f < 0 && (fc.background_u8 >> 24)) {
+        // background: the host already finalised the colour with NumPy itself (obj/core.py:600,640)
+        if (a.frame) { a.frame[at * 3 + 0] = rgb[0]; a.frame[at * 3 + 1] = rgb[1]; a.frame[at * 3 + 2] = rgb[2]; }
+        uint8_t *o = a.out + ((size_t)(fc.band_y1 - 1 - py) * W + px) * 3;
+        o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
+        return;
+    }
     if (f >= 0) {
         const bool lit = (int16_t)a.stencil[at] == 0;
         const TriRec t = a.tris[f];
@@ -144,8 +183,9 @@ k_shade(const FrameConst fc, const ShadeArgs a)
             dl[j] = fc.light_pos[j] - pos[j];
         }
         // Light.attenuation (obj/core.py:517-524)
-        const double dist = sqrt((dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2]);
-        const double att = 1.0 / (fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
+        const double dl2 = (dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2];
+        const double dist = dl2 > 0 ? dl2 * c_rsqrt(dl2) : 0.0;
+        const double att = c_rcp(fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
 
         if (!lit) {
 #pragma unroll
@@ -165,7 +205,7 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                 const float *tx = texel(a.textures[mat.tex_norm], a.uv, ti, p);
                 if (mat.norm_tangent) {
                     double n[3], A[3][3], AI[3][3];
-                    normalize3(interp, n);
+                    c_normalize3(interp, n);
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         if (ff & FF_VERTS_F32) {
@@ -189,8 +229,8 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                         ti_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], du[0], du[1], 0.0);
                         tj_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], dv[0], dv[1], 0.0);
                     }
-                    normalize3(ti_, T);
-                    normalize3(tj_, Bt);
+                    c_normalize3(ti_, T);
+                    c_normalize3(tj_, Bt);
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
                         raw[r] = chain3(T[r], Bt[r], n[r], (double)tx[0], (double)tx[1], (double)tx[2]);
@@ -215,24 +255,24 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                     for (int j = 0; j < 3; ++j) { e0[j] = wb[j] - wa[j]; e1[j] = wc[j] - wa[j]; }
                     double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
                                      e0[0] * e1[1] - e0[1] * e1[0] };
-                    normalize3(cr, fn);
+                    c_normalize3(cr, fn);
                 }
                 for (int j = 0; j < 3; ++j) raw[j] = chain3(p[0], p[1], p[2], fn[j], fn[j], fn[j]);
             }
             double N[3], L[3], V[3], Hh[3], tmp[3];
-            normalize3(raw, N);
+            c_normalize3(raw, N);
 
             // ---- Blinn-Phong (obj/triangular.py:151-171)
             if (fc.light_type == MR_LIGHT_DIRECTIONAL) {
                 L[0] = fc.light_dir[0]; L[1] = fc.light_dir[1]; L[2] = fc.light_dir[2];
             } else {
-                normalize3(dl, L);
+                c_normalize3(dl, L);
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) tmp[j] = fc.camera_pos[j] - pos[j];
-            normalize3(tmp, V);
+            c_normalize3(tmp, V);
             if (fc.light_type == MR_LIGHT_SPOT) {
-                double x = (sum3(fc.light_dir, L) - fc.spot_edge0) / (fc.spot_edge1 - fc.spot_edge0);
+                double x = (sum3(fc.light_dir, L) - fc.spot_edge0) * c_rcp(fc.spot_edge1 - fc.spot_edge0);
                 x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
                 const double in_light = x * x * (3 - 2 * x);
 #pragma unroll
@@ -248,7 +288,7 @@ k_shade(const FrameConst fc, const ShadeArgs a)
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) tmp[j] = L[j] + V[j];
-            normalize3(tmp, Hh);
+            c_normalize3(tmp, Hh);
             double nh = sum3(N, Hh);
             nh = nh < 0 ? 0 : nh;
             const double refl = np_power(nh, mat.ns);

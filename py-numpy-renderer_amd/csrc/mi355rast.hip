@@ -220,6 +220,7 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
         fc.light_color[j] = fr->light_color[j]; fc.light_ambient[j] = fr->light_ambient[j];
         fc.background[j] = fr->background[j];
     }
+    fc.background_u8 = (uint32_t)fr->background_u8;
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
     fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;
@@ -296,11 +297,14 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
         HIP_TRY(hipEventRecord(sc->ev[1], stream));
     }
     HIP_TRY(hipEventRecord(sc->ev[2], stream));
-    if (shadows && fc.n_edges > 0)
-        hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 128)), dim3(128), 0, stream, fc,
+    if (shadows && fc.n_edges > 0) {
+        hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 256)), dim3(256), 0, stream, fc,
                            sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
-                           sc->d_lit.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
-                           sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
+                           sc->d_lit.as<uint8_t>(), sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
+        hipLaunchKernelGGL(k_quad_setup, dim3(blocks_for(std::min<long long>(fc.n_edges, sc->quad_cap), 64)), dim3(64),
+                           0, stream, fc, sc->d_sil.as<int32_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
+                           sc->quad_cap, ctr);
+    }
     HIP_TRY(hipEventRecord(sc->ev[3], stream));
 
     // ---- binning: classify + count, large-primitive count, scan, fill, large-primitive fill

@@ -55,7 +55,7 @@ struct FrameConst {
     double specular_strength, att_constant, att_linear, att_quadratic;
     double spot_edge0, spot_edge1;
     float background[3];
-    int32_t pad;
+    uint32_t background_u8;      // finalised background r | g << 8 | b << 16 | 1 << 24 (0 = not given)
 };
 
 // Output of the vertex kernel: everything obj/triangular.py:36-45 derives per face corner,
