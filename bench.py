@@ -37,15 +37,17 @@ def algorithmic_bytes(st, npx, n_faces, textured_spec=False):
     "fragments that passed z" counts (they are lower bounds, so the figure is conservative)."""
     f_tri, f_quad = st["frag_tri"], st["frag_quad"]
     covered, lit, upd = st["covered_px"], st["lit_px"], st["stencil_updates"]
-    visibility = (8 * f_tri + 8 * covered            # pass 1: z read per fragment, z write per pass
-                  + 10 * f_tri                       # pass 2: z + stencil read per fragment
-                  + 8 * f_quad + 4 * upd             # quads: z read, stencil read-modify-write
-                  + 10 * npx)                        # clear of z (8) and stencil (2)
+    visibility_tris = (8 * f_tri + 8 * covered       # pass 1: z read per fragment, z write per pass
+                       + 10 * f_tri                  # pass 2: z + stencil read per fragment
+                       + 10 * npx)                   # clear of z (8) and stencil (2)
+    visibility_quads = 8 * f_quad + 4 * upd          # quads: z read, stencil read-modify-write
+    visibility = visibility_tris + visibility_quads
     shading = ((12 + 12) * covered                   # pass 1: Kd texel + colour write
                + (12 + 12 + 12 + (4 if textured_spec else 0)) * lit   # pass 2: Kd + normal texel + write
                + (12 + 15) * npx)                    # frame clear (12) + finalise read 12 / write 3
     primitives = 2 * (120 + 48) * n_faces + 32 * st["n_quads"]        # attributes + indices per pass
-    return dict(visibility=visibility, shading=shading, primitives=primitives,
+    return dict(visibility=visibility, visibility_tris=visibility_tris, visibility_quads=visibility_quads,
+                shading=shading, primitives=primitives,
                 total=visibility + shading + primitives)
 
 
@@ -75,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-marks", action="store_true", help="time every stage (9 event marks per frame instead of 5)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +112,7 @@ def main():
     frags_per_frame = 2 * full["frag_tri"] + full["frag_quad"]
     frags_unique = full["frag_tri"] + full["frag_quad"]
 
-    br = BandRenderer(scene, rank, world, shadows=True)
+    br = BandRenderer(scene, rank, world, shadows=True, light_timing=not args.all_marks)
     rows = br.band[1] - br.band[0]
     frame, step = br.frame, br.step
 
@@ -145,7 +148,7 @@ def main():
 
         ms = elapsed / args.steps * 1e3
         alg = algorithmic_bytes(band_stats, W * rows, n_faces)
-        kernel_alg = {"tile_raster": alg["visibility"], "shade": alg["shading"]}
+        kernel_alg = {"tile_raster": alg["visibility_tris"], "tile_quads": alg["visibility_quads"], "shade": alg["shading"]}
         dominant = max(kernel_alg, key=lambda k: ktimes[k])
         k_ms = ktimes[dominant]
         achieved = kernel_alg[dominant] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0

@@ -46,7 +46,8 @@ enum {
 enum {
     MR_FRAME_SHADOWS = 1,     /* run the shadow-volume stencil pass (obj/core.py:610-622) */
     MR_FRAME_KEEP_FLOAT = 2,  /* also keep the float32 frame (needed by mr_read_frame_f32) */
-    MR_FRAME_FACE_STATUS = 4  /* also compute the per-face status histogram (obj/core.py:625-636) */
+    MR_FRAME_FACE_STATUS = 4, /* also compute the per-face status histogram (obj/core.py:625-636) */
+    MR_FRAME_LIGHT_TIMING = 8 /* record only the event marks around the frame and the visibility kernels */
 };
 
 typedef struct mr_scene mr_scene;
@@ -128,6 +129,10 @@ int mr_device_available(void);
 
 int mr_abi_version(void);
 
+/* sizeof() of the ABI structs as this build sees them (0 mr_frame_desc, 1 mr_material,
+ * 2 mr_model_desc, 3 mr_stats; -1 otherwise), so a binding can verify its own layout. */
+int mr_abi_struct_size(int which);
+
 /* Scene() -- obj/core.py:563-582.  Returns NULL on failure. */
 mr_scene *mr_scene_create(void);
 void mr_scene_destroy(mr_scene *scene);
@@ -159,10 +164,13 @@ int mr_get_stats(mr_scene *scene, mr_stats *stats);
 
 /* Average device time in milliseconds (HIP events on the stream the kernels ran on) of each
  * stage over the last n_frames frames, most recent first; at most 128 are remembered.
- *   [0] k_vertex + k_tri_setup   [1] k_tri_count   [2] k_silhouette   [3] triangle binning (3 kernels)
- *   [4] quad binning (3 kernels) [5] k_tile_raster [6] k_shade        [7] whole frame (start -> after k_shade)
+ *   [0] k_vertex + k_tri_setup     [1] k_tri_count     [2] k_silhouette + k_quad_setup
+ *   [3] binning, count passes      [4] binning, scan + fill passes
+ *   [5] k_tile_raster              [6] k_tile_quads    [7] k_shade
+ *   [8] whole frame (start -> after k_shade)
+ * Frames rendered with MR_FRAME_LIGHT_TIMING report [0..4] as 0.
  * Synchronises the device.  Returns the number of frames averaged or a negative error. */
-#define MR_N_KERNEL_TIMES 8
+#define MR_N_KERNEL_TIMES 9
 int mr_get_kernel_times(mr_scene *scene, int n_frames, float *out_ms, int cap);
 
 /* Debug taps for parity tests: the reference's working buffers after the last render

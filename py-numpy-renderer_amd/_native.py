@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MR_OK = 0
 MR_E_OVERFLOW = -4
-FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS = 1, 2, 4
+FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING = 1, 2, 4, 8
 
 
 class FrameDesc(C.Structure):
@@ -64,6 +64,7 @@ _PROTOTYPES = {
     "mr_init": (C.c_int, [C.c_int]),
     "mr_device_available": (C.c_int, []),
     "mr_abi_version": (C.c_int, []),
+    "mr_abi_struct_size": (C.c_int, [C.c_int]),
     "mr_scene_create": (C.c_void_p, []),
     "mr_scene_destroy": (None, [C.c_void_p]),
     "mr_scene_add_texture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -98,6 +99,10 @@ def load_library():
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        for which, struct in enumerate((FrameDesc, MaterialDesc, ModelDesc, Stats)):
+            if lib.mr_abi_struct_size(which) != C.sizeof(struct):
+                raise RuntimeError(f"{LIB_NAME}: layout of {struct.__name__} differs from the binding "
+                                   f"({lib.mr_abi_struct_size(which)} vs {C.sizeof(struct)} bytes); rebuild")
         _lib = lib
     return _lib
 
@@ -109,11 +114,12 @@ def _check(rc, what):
     return rc
 
 
-def fill_frame_desc(pf, row_band=None, keep_float=False):
+def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False):
     d = FrameDesc()
     d.width, d.height, d.system = pf.width, pf.height, pf.system
     d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
-    d.flags = (FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
+    d.flags = ((FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
+               | (FRAME_LIGHT_TIMING if light_timing else 0))
     d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
     for name in ("mvp", "viewport", "debug_mvp", "frustum_planes", "camera_pos", "light_pos", "light_dir",
                  "light_color", "light_ambient"):
@@ -198,11 +204,11 @@ class DeviceRenderer:
         self._frame = (pf.height, pf.width)
         return out
 
-    def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None):
+    def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False):
         """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
         self.sync_scene(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, False)
+        desc = fill_frame_desc(pf, row_band, False, light_timing)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
         self._frame = (pf.height, pf.width)
@@ -220,13 +226,13 @@ class DeviceRenderer:
         self.last_stats = st.as_dict()
         return self.last_stats
 
-    KERNEL_TIME_NAMES = ("vertex+tri_setup", "tri_count", "silhouette", "bin_tris", "bin_quads",
-                         "tile_raster", "shade", "frame")
+    KERNEL_TIME_NAMES = ("vertex+tri_setup", "tri_count", "silhouette+quad_setup", "bin_count", "bin_scan_fill",
+                         "tile_raster", "tile_quads", "shade", "frame")
 
     def kernel_times(self, n_frames):
         """Average per-stage device milliseconds over the last *n_frames* frames (syncs)."""
-        buf = (C.c_float * 8)()
-        n = _check(self.lib.mr_get_kernel_times(self.handle, int(n_frames), buf, 8), "mr_get_kernel_times")
+        buf = (C.c_float * 9)()
+        n = _check(self.lib.mr_get_kernel_times(self.handle, int(n_frames), buf, 9), "mr_get_kernel_times")
         return dict(zip(self.KERNEL_TIME_NAMES, (float(v) for v in buf))), n
 
     # -- debug taps -----------------------------------------------------------------------

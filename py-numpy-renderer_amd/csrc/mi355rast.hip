@@ -97,9 +97,9 @@ struct mr_scene {
     mr::Counters *h_counters = nullptr;      // pinned
     // Event marks of the last EVENT_RING frames (frames are enqueued without host syncs, so a
     // bench that times K frames can still average each kernel's duration over them afterwards).
-    // Marks: 0 start | 1 vertex+tri_setup | 2 tri_count | 3 silhouette | 4 triangle bins |
-    //        5 quad bins | 6 tile raster | 7 shade | 8 device->host copy
-    static constexpr int EVENT_RING = 128, N_MARKS = 9;
+    // Marks: 0 start | 1 vertex+tri_setup | 2 tri_count | 3 silhouette+quad_setup | 4 bin count |
+    //        5 bin scan+fill | 6 tile raster | 7 tile quads | 8 shade | 9 device->host copy
+    static constexpr int EVENT_RING = 128, N_MARKS = 10;
     hipEvent_t ev_ring[EVENT_RING][N_MARKS] = {};
     hipEvent_t *ev = ev_ring[0];
     uint64_t frames_enqueued = 0;
@@ -273,6 +273,8 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     sc->ev = sc->ev_ring[sc->frames_enqueued % mr_scene::EVENT_RING];
 
     Counters *ctr = sc->d_counters.as<Counters>();
+    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the visibility kernels
+    const bool all_marks = !(fc.flags & MR_FRAME_LIGHT_TIMING);
     HIP_TRY(hipEventRecord(sc->ev[0], stream));
     // The bin cursors are left zeroed by k_tile_raster and the frame counters are cleared by
     // k_vertex, so a steady-state frame issues no memset; only a new tile grid needs one.
@@ -289,14 +291,14 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
                            sc->d_vout.as<VertexOut>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
                            sc->d_status.as<uint8_t>(), sc->d_lit.as<uint8_t>(), sc->d_valid.as<uint32_t>(), ctr);
-        HIP_TRY(hipEventRecord(sc->ev[1], stream));
+        if (all_marks) HIP_TRY(hipEventRecord(sc->ev[1], stream));
         hipLaunchKernelGGL(k_tri_count, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream,
                            fc, sc->d_valid.as<uint32_t>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
                            sc->d_status.as<uint8_t>(), ctr);
     } else {
-        HIP_TRY(hipEventRecord(sc->ev[1], stream));
+        if (all_marks) HIP_TRY(hipEventRecord(sc->ev[1], stream));
     }
-    HIP_TRY(hipEventRecord(sc->ev[2], stream));
+    if (all_marks) HIP_TRY(hipEventRecord(sc->ev[2], stream));
     if (shadows && fc.n_edges > 0) {
         hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 256)), dim3(256), 0, stream, fc,
                            sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
@@ -305,7 +307,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                            0, stream, fc, sc->d_sil.as<int32_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
                            sc->quad_cap, ctr);
     }
-    HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    if (all_marks) HIP_TRY(hipEventRecord(sc->ev[3], stream));
 
     // ---- binning: classify + count, large-primitive count, scan, fill, large-primitive fill
     BinArgs ba;
@@ -321,7 +323,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     const unsigned large_blocks = 1024;      // grid-stride over the work items, 4 wavefronts per block
     hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
     hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
-    HIP_TRY(hipEventRecord(sc->ev[4], stream));
+    if (all_marks) HIP_TRY(hipEventRecord(sc->ev[4], stream));
     hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_bin_count.as<uint32_t>(),
                        sc->d_bin_offset.as<uint32_t>(), n_tiles, sc->item_cap, ctr);
     hipLaunchKernelGGL((k_bin_classify<true>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
@@ -335,11 +337,12 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
                        sc->d_bin_offset.as<uint32_t>(), sc->d_items.as<uint32_t>(), sc->item_cap,
                        sc->d_bin_count.as<uint32_t>(), sc->d_z.as<double>(), sc->d_winner.as<int32_t>(),
                        sc->d_stencil.as<int32_t>(), sc->d_tile_stats.as<uint32_t>());
+    HIP_TRY(hipEventRecord(sc->ev[6], stream));
     if (shadows)
         hipLaunchKernelGGL(k_tile_quads, dim3(2048), dim3(TILE_PX), 0, stream, fc, sc->d_quads.as<QuadRec>(),
                            sc->d_quad_work.as<uint4>(), sc->quad_work_cap, sc->d_items.as<uint32_t>(), sc->item_cap,
                            sc->d_z.as<double>(), sc->d_stencil.as<int32_t>(), sc->d_tile_stats.as<uint32_t>(), ctr);
-    HIP_TRY(hipEventRecord(sc->ev[6], stream));
+    HIP_TRY(hipEventRecord(sc->ev[7], stream));
 
     // ---- deferred shading + finalise
     ShadeArgs sa;
@@ -352,7 +355,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
     sa.out = d_out;
     const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(band_px, 256)), dim3(256), 0, stream, fc, sa);
-    HIP_TRY(hipEventRecord(sc->ev[7], stream));
+    HIP_TRY(hipEventRecord(sc->ev[8], stream));
     HIP_TRY(hipGetLastError());
     sc->last_frame = *fr;
     sc->last_n_tiles = n_tiles;
@@ -392,10 +395,11 @@ int collect(mr_scene *sc, bool with_copy)
     sc->n_silhouette = (int)c.n_quads;
     float ms = 0;
     auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, sc->ev[a], sc->ev[b]); return ms; };
-    s.gpu_ms_geometry = span(0, 3); s.gpu_ms_binning = span(3, 5); s.gpu_ms_raster = span(5, 6);
-    s.gpu_ms_shade = span(6, 7);
-    s.gpu_ms_copy = with_copy ? span(7, 8) : 0.f;
-    s.gpu_ms_total = span(0, with_copy ? 8 : 7);
+    const bool light = (sc->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
+    s.gpu_ms_geometry = light ? 0.f : span(0, 3); s.gpu_ms_binning = light ? 0.f : span(3, 5);
+    s.gpu_ms_raster = span(5, 7); s.gpu_ms_shade = span(7, 8);
+    s.gpu_ms_copy = with_copy ? span(8, 9) : 0.f;
+    s.gpu_ms_total = span(0, with_copy ? 9 : 8);
     if (c.overflow) {
         const uint32_t entries = c.tri_bin_total + c.quad_bin_total;
         if (c.overflow & 1u) { sc->item_cap = entries + entries / 2 + 1024; }
@@ -425,6 +429,17 @@ int read_back(mr_scene *sc, const DevBuf &buf, T *out, size_t count, const char 
 extern "C" {
 
 int mr_abi_version(void) { return MR_ABI_VERSION; }
+
+int mr_abi_struct_size(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(mr_frame_desc);
+    case 1: return (int)sizeof(mr_material);
+    case 2: return (int)sizeof(mr_model_desc);
+    case 3: return (int)sizeof(mr_stats);
+    default: return -1;
+    }
+}
 
 int mr_device_available(void)
 {
@@ -570,7 +585,7 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
         if ((rc = enqueue_frame(sc, fr, sc->d_out.as<uint8_t>(), g_stream))) return rc;
         if ((rc = fetch_counters(sc, g_stream))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipEventRecord(sc->ev[8], g_stream));
+        HIP_TRY(hipEventRecord(sc->ev[9], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         rc = collect(sc, true);
         if (rc == MR_OK) {
@@ -614,15 +629,16 @@ int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
     const uint64_t have = std::min<uint64_t>(sc->frames_enqueued, mr_scene::EVENT_RING);
     const uint64_t n = std::min<uint64_t>(have, n_frames > 0 ? (uint64_t)n_frames : 1);
     double acc[MR_N_KERNEL_TIMES] = {};
+    const bool light = (sc->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
     for (uint64_t i = 0; i < n; ++i) {
         hipEvent_t *ev = sc->ev_ring[(sc->frames_enqueued - 1 - i) % mr_scene::EVENT_RING];
         float ms;
-        for (int k = 0; k < 7; ++k) {
+        for (int k = light ? 5 : 0; k < 8; ++k) {
             ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
             acc[k] += ms;
         }
-        ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[7]);
-        acc[7] += ms;
+        ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[8]);
+        acc[8] += ms;
     }
     for (int k = 0; k < MR_N_KERNEL_TIMES; ++k) out_ms[k] = (float)(acc[k] / (double)n);
     return (int)n;

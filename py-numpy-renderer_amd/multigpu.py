@@ -41,7 +41,7 @@ def all_gather_frame(part, frame=None, group=None):
 class BandRenderer:
     """Per-rank driver: render this rank's band into HBM, then all-gather the frame."""
 
-    def __init__(self, scene, rank=0, world=1, shadows=True):
+    def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False):
         height, width = (int(v) for v in scene.resolution)
         self.rank, self.world = rank, world
         self.band = row_band(height, rank, world)
@@ -52,7 +52,7 @@ class BandRenderer:
         self.part = self.frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
         with torch.cuda.stream(self.stream):
             self.desc = self.backend.render_device(scene, self.part.data_ptr(), self.stream.cuda_stream,
-                                                   shadows=shadows, row_band=self.band)
+                                                   shadows=shadows, row_band=self.band, light_timing=light_timing)
         self.stream.synchronize()
 
     def step(self):

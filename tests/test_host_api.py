@@ -1,0 +1,107 @@
+"""CPU suite: host-side mirror of the reference API (no GPU, no oracle).
+
+The per-frame constants the device consumes (MVP, viewport, debug MVP, frustum planes, light
+direction) are compared bit for bit with what the reference computed for the same scenes
+(the ``host_*`` arrays in tests/golden/*.npz); loader rules are checked on small OBJ texts."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from conftest import load_golden
+from py_numpy_renderer_amd import Camera, Light, Lightning, Material, Model, Scene, SYSTEM, SUBSYSTEM
+from py_numpy_renderer_amd import transformation as tr
+from py_numpy_renderer_amd._pack import pack_scene
+from py_numpy_renderer_amd.plane_intersection import clipping, extract_frustum_planes
+
+
+@pytest.mark.parametrize("name", list(scenes.SMALL) + list(scenes.FULL))
+def test_frame_constants_match_reference(api, name):
+    g, _ = load_golden(name)
+    f = pack_scene(scenes.build(api, name)).frame
+    assert np.array_equal(f.mvp, g["host_mvp"])
+    assert np.array_equal(f.viewport, g["host_viewport"])
+    assert np.array_equal(f.debug_mvp, g["host_debug_mvp"])
+    assert np.array_equal(f.frustum_planes, g["host_planes"])
+    assert np.array_equal(f.light_dir, g["host_light_dir"])
+
+
+def test_projection_table_and_viewport():
+    for sub in (SUBSYSTEM.DIRECTX, SUBSYSTEM.OPENGL):
+        for sysm in (SYSTEM.RH, SYSTEM.LH):
+            m = tr.perspectives[sub][1][sysm](60, 16 / 9, 0.1, 20)
+            assert m.shape == (4, 4) and m[2, 3] == (-1.0 if sysm == SYSTEM.RH else 1.0)
+            assert m[0, 0] == pytest.approx(1 / np.tan(np.radians(30)) / (16 / 9))
+    vp = tr.ViewPort((1080, 1920), 20, 0.1, x_offset=3, y_offset=-2)
+    assert vp[0, 0] == 960 and vp[1, 1] == 540 and vp[3, 0] == 963 and vp[3, 1] == 538 and vp[3, 2] == vp[2, 2]
+
+
+def test_model_transforms_keep_reference_dtypes(api):
+    cube = Model.load_model(os.path.join(scenes.ASSETS, "cube", "cube.obj"))
+    assert cube.vertices.dtype == np.float32 and cube.vertices.shape == (8, 4)
+    assert (cube @ tr.scale(0.5)).vertices.dtype == np.float64        # float32 @ float64 promotes
+    assert tr.scale(2).dtype.kind == "i" and tr.translation((0, -1.2, 0)).dtype == np.float64
+    assert tr.rotate_xyz((10, 20, 30)).dtype == np.float32
+    packed = pack_scene(_one_model_scene(cube))
+    assert packed.models[0].vertices_are_f32 is False and packed.models[0].vertices.dtype == np.float64
+
+
+def _one_model_scene(model):
+    cam = Camera((0.5, 1, 2), (0, 0, 0), fovy=60, near=0.1, far=20)
+    sc = Scene(cam, Light((2, 3, 4)), debug_camera=None, resolution=(12, 16))
+    sc.add_model(model)
+    return sc
+
+
+def test_obj_loader_rules(tmp_path):
+    text = ("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\n"
+            "usemtl red\nf 1/1/1 2/2/1 3/3/1 4/4/1\nusemtl default\nf -4/-4/-1 -3/-3/-1 -2/-2/-1\nf 1//1 2//1 3//1\n")
+    (tmp_path / "m.mtl").write_text("newmtl red\nKd 1 0 0\nNs 10\nKs 0.5\nmap_Kd missing.png\n")
+    (tmp_path / "q.obj").write_text(text)
+    m = Model.load_model(str(tmp_path / "q.obj"))
+    assert m.vertices.shape == (4, 4) and (m.vertices[:, 3] == 1).all()          # w = 1 appended
+    assert m.uv.shape == (4, 3) and (m.uv[:, 2] == 0).all()                     # vt padded
+    assert m._faces.shape == (4, 3, 4)                                           # quad -> fan of 2
+    assert m._faces[0].tolist() == [[0, 0, 0, 1], [1, 1, 0, 1], [2, 2, 0, 1]]    # 0-based, material group 1
+    assert m._faces[1][:, 0].tolist() == [0, 2, 3]
+    assert m._faces[2][:, 0].tolist() == [-4, -3, -2]                           # negative indices stay relative
+    assert m._faces[3][:, 1].tolist() == [-1, -1, -1]                           # missing vt -> -1
+    assert m.material_group == ["default", "red"]
+    red = m.face_material(1)
+    assert red.Ns == 10.0 and red.Ks == 0.5 and red.Kd.dtype == np.float32 and not hasattr(red, "map_Kd")
+    packed = pack_scene(_one_model_scene(m))
+    assert packed.models[0].faces.min() >= 0 and packed.models[0].faces[2][:, 0].tolist() == [0, 1, 2]
+    assert packed.models[0].materials[1].ks255.tolist() == [127.5] * 3
+
+
+def test_material_and_texture_register(api):
+    mat = Material()
+    assert mat.Ns == 64 and not hasattr(mat, "map_Kd")
+    with pytest.raises(AttributeError):
+        mat.nonsense
+    floor = scenes._floor(api)
+    tex = floor.materials["default"].map_Kd
+    assert tex.dtype == np.float32 and tex.ndim == 3 and 0 <= tex.min() and tex.max() <= 1
+    floor.textures.register("normals", os.path.join(scenes.ASSETS, "floor_nm_tangent.tga"), tangent=True)
+    assert floor.materials["default"].is_tangent_space("norm") and floor.materials["default"].norm.min() < 0
+    with pytest.raises(ValueError):
+        floor.textures.register("glow", "x.png")
+
+
+def test_clipping_matches_reference_examples():
+    planes = extract_frustum_planes(np.eye(4))                   # the unit cube |x|,|y|,|z| <= w
+    quad = np.array([[-2, -0.5, 0, 1], [2, -0.5, 0, 1], [2, 0.5, 0, 1], [-2, 0.5, 0, 1]], dtype=float)
+    out = clipping(quad, planes)
+    assert out.shape == (4, 4) and np.abs(out[:, 0]).max() == pytest.approx(1.0)
+    assert clipping(quad + [5, 0, 0, 0], planes).shape[0] == 0    # fully outside -> empty
+
+
+def test_scene_api_surface(api):
+    sc = scenes.cube_small(api)
+    assert sc.resolution == (120, 160) and sc.camera.scene is sc and sc.debug_camera.scene is sc
+    assert sc.camera.MVP is sc.camera.MVP                         # cached like the reference
+    with pytest.raises(NotImplementedError):
+        Scene(Camera((0, 0, 1), (0, 0, 0), show=True), Light((1, 1, 1)))
+    assert Light((1, 2, 3)).light_type is Lightning.POINT_LIGHTNING
+    assert Light((1, 1, 1), ambient_strength=0.1).ambient.tolist() == [0.1, 0.1, 0.1]
