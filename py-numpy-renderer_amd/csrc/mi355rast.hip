@@ -303,7 +303,7 @@ int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStre
         hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 256)), dim3(256), 0, stream, fc,
                            sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
                            sc->d_lit.as<uint8_t>(), sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
-        hipLaunchKernelGGL(k_quad_setup, dim3(blocks_for(std::min<long long>(fc.n_edges, sc->quad_cap), 64)), dim3(64),
+        hipLaunchKernelGGL(k_quad_setup, dim3((unsigned)std::min<long long>(1024, blocks_for(std::min<long long>(fc.n_edges, sc->quad_cap) * QS_LANES, 64))), dim3(64),
                            0, stream, fc, sc->d_sil.as<int32_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
                            sc->quad_cap, ctr);
     }

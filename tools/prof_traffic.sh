@@ -1,0 +1,21 @@
+#!/bin/bash
+# GPU box: HBM traffic counters per kernel, two separate --pmc passes (FETCH_SIZE uses 3 of the 4 TCC slots).
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc/traffic
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 > $out/fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 > $out/write.log 2>&1
+python3 - "$out" <<'PY'
+import csv, glob, sys, json, collections
+res = collections.defaultdict(dict)
+for kind in ("fetch", "write"):
+    f = glob.glob(f"{sys.argv[1]}/{kind}/*/*_counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mr::", "")].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        res[k][kind] = sum(v) / len(v)
+for k, v in sorted(res.items()):
+    print(f"{k:32s} FETCH_SIZE={v.get('fetch', 0):12.1f} WRITE_SIZE={v.get('write', 0):12.1f}")
+json.dump(res, open(sys.argv[1] + "/traffic_raw.json", "w"), indent=1)
+PY
