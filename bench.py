@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-marks", action="store_true", help="time every stage (9 event marks per frame instead of 5)")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="successive frames rendered on this many HIP streams (1 = one frame at a time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,9 +114,10 @@ def main():
     frags_per_frame = 2 * full["frag_tri"] + full["frag_quad"]
     frags_unique = full["frag_tri"] + full["frag_quad"]
 
-    br = BandRenderer(scene, rank, world, shadows=True, light_timing=not args.all_marks)
+    br = BandRenderer(scene, rank, world, shadows=True, light_timing=not args.all_marks,
+                      frames_in_flight=args.frames_in_flight)
     rows = br.band[1] - br.band[0]
-    frame, step = br.frame, br.step
+    step = br.step
 
     for _ in range(args.warmup):
         step()
@@ -142,7 +145,7 @@ def main():
     if rank == 0:
         # the frame every rank now holds must be the frame a single device renders
         import numpy as np
-        got = frame.cpu().numpy()
+        got = br.frame.cpu().numpy()
         want = backend.render(scene, shadows=True)
         assert np.array_equal(got, want), "assembled frame differs from the single-device frame"
 
@@ -172,7 +175,8 @@ def main():
             "config": {"workload": "torus 500x200 (200k tris) + floor, 1920x1080, point light, shadow volumes "
                                    "(BASELINE.json configs[3] / BASELINE.md c4)",
                        "fragments_per_frame": frags_per_frame, "unique_fragments_per_frame": frags_unique,
-                       "faces": n_faces, "parallelism": f"screen row bands x{world}"
+                       "faces": n_faces, "frames_in_flight": args.frames_in_flight,
+                       "parallelism": f"screen row bands x{world}"
                                                          + (" + 1 RCCL all-gather" if world > 1 else "")},
             "mfrag_unique_per_s": round(frags_unique / (elapsed / args.steps) / 1e6, 2),
             "gpu_ms_per_kernel": {k: round(v, 4) for k, v in ktimes.items()},

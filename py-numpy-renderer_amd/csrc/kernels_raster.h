@@ -561,9 +561,28 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
             const unsigned long long m = __ballot(in);
             if (!m) continue;
             qfrags += (unsigned int)__popcll(m);
-            double z = -((bcast(m_nx, j) * dpx + bcast(m_ny, j) * dpy) + bcast(m_d, j)) / bcast(m_nz, j);
-            z = linearize_z(fc, z);
-            const bool pass = in && (rh ? (zbest >= z) : (zbest <= z));
+            // Depth of the quad at the sample and the test against the z-buffer
+            // (obj/triangular.py:351-360).  The reference's value needs two IEEE divisions; the
+            // DECISION almost never does: an approximation good to 2e-10 (Newton-refined
+            // v_rcp_f64) settles it unless z-buffer and quad depth agree to nine digits, and
+            // only then is the exactly rounded expression evaluated.  Decisions stay bit-exact.
+            const double t = (bcast(m_nx, j) * dpx + bcast(m_ny, j) * dpy) + bcast(m_d, j);
+            const double nzq = bcast(m_nz, j);
+            const double zs_a = -t * approx_rcp(nzq);
+            const double m_a = zs_a * fc.f_minus_n;
+            const double den_a = fc.f_plus_n - m_a;
+            const double zq_a = fc.two_nf * approx_rcp(den_a);
+            const double diff = zbest - zq_a;
+            bool pass = rh ? diff > 0 : diff < 0;
+            // not decided: close call, denominator near its pole, or a non-finite intermediate
+            const bool unsure = in && !(fabs(diff) > 2e-10 * fabs(zq_a) && fabs(den_a) > 2e-4 * fabs(m_a));
+            if (__ballot(unsure)) {
+                if (unsure) {
+                    const double z = linearize_z(fc, -t / nzq);
+                    pass = rh ? (zbest >= z) : (zbest <= z);
+                }
+            }
+            pass = pass && in;
             qupd += (unsigned int)__popcll(__ballot(pass));
             sten += pass ? (front ? 1 : -1) : 0;
         }

@@ -2,10 +2,15 @@
 //
 // One process drives one GPU.  A scene keeps its static arrays (vertices, attributes, index
 // arrays, textures, the unique-edge table for silhouettes) resident in HBM; a frame is a fixed
-// sequence of kernels on one HIP stream:
+// sequence of kernels on one HIP stream, with no host synchronisation in between:
 //
-//   k_vertex -> k_tri_setup -> k_tri_count -> [k_silhouette] -> bin(count, scan, fill) x {tris, quads}
-//            -> k_tile_raster -> k_shade -> (D2H of the uint8 band)
+//   k_vertex -> k_tri_setup -> k_tri_count -> [k_silhouette -> k_quad_setup]
+//     -> k_bin_classify<count> -> k_bin_large<count> -> k_scan_bins -> k_bin_classify<fill> -> k_bin_large<fill>
+//     -> k_tile_raster -> [k_tile_quads] -> k_shade -> (D2H of the uint8 band for mr_render)
+//
+// Per-frame work buffers live in a "frame slot".  Every stream a caller renders on gets its own
+// slot, so frames enqueued on different streams are independent and may overlap on the device
+// (the stages of one frame are short, latency-bound kernels that leave most CUs idle).
 //
 // Built for gfx950 only, with -ffp-contract=off (see rast_math.h).
 #include "../../include/mi355rast.h"
@@ -16,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -71,6 +77,47 @@ struct EdgeKey {
     uint32_t inc;      // face * 4 + corner
 };
 
+// Event marks of one frame:
+//   0 start | 1 vertex+tri_setup | 2 tri_count | 3 silhouette+quad_setup | 4 bin count passes |
+//   5 bin scan+fill | 6 tile raster | 7 tile quads | 8 shade | 9 device->host copy
+constexpr int EVENT_RING = 64, N_MARKS = 10;
+
+// Everything one in-flight frame writes.
+struct FrameSlot {
+    hipStream_t stream = nullptr;                 // the stream this slot serves
+    DevBuf d_vout, d_tris, d_clips, d_status, d_lit, d_valid, d_quads, d_sil, d_counters;
+    DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_quad_work, d_tile_stats;
+    DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
+    uint32_t item_cap = 0, work_cap = 0, quad_cap = 0, quad_work_cap = 0;
+    int bins_zeroed_for = 0;
+
+    mr::Counters *h_counters = nullptr;           // pinned
+    hipEvent_t ev_ring[EVENT_RING][N_MARKS] = {};
+    hipEvent_t *ev = ev_ring[0];
+    uint64_t frames_enqueued = 0;
+    bool events_ok = false;
+
+    mr_frame_desc last_frame = {};
+    int last_n_tiles = 0;
+    bool have_frame = false, stats_reduced = false;
+
+    void reset_caps() { item_cap = work_cap = quad_cap = quad_work_cap = 0; bins_zeroed_for = 0; have_frame = false; }
+    void release()
+    {
+        DevBuf *bufs[] = { &d_vout, &d_tris, &d_clips, &d_status, &d_lit, &d_valid, &d_quads, &d_sil, &d_counters,
+                           &d_bin_count, &d_bin_offset, &d_items, &d_work, &d_quad_work, &d_tile_stats,
+                           &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
+        for (DevBuf *b : bufs) b->release();
+        if (events_ok) {
+            for (auto &set : ev_ring) for (auto &e : set) (void)hipEventDestroy(e);
+            (void)hipHostFree(h_counters);
+            events_ok = false;
+        }
+    }
+};
+
+constexpr int MAX_SLOTS = 8;
+
 }  // namespace
 
 struct mr_scene {
@@ -88,26 +135,10 @@ struct mr_scene {
 
     // ---- device copies of the static scene
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
-    // ---- per-frame work buffers
-    DevBuf d_vout, d_tris, d_clips, d_status, d_lit, d_valid, d_quads, d_sil, d_counters;
-    DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_quad_work, d_tile_stats;
-    DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
-    uint32_t item_cap = 0, work_cap = 0, quad_cap = 0, quad_work_cap = 0;
 
-    mr::Counters *h_counters = nullptr;      // pinned
-    // Event marks of the last EVENT_RING frames (frames are enqueued without host syncs, so a
-    // bench that times K frames can still average each kernel's duration over them afterwards).
-    // Marks: 0 start | 1 vertex+tri_setup | 2 tri_count | 3 silhouette+quad_setup | 4 bin count |
-    //        5 bin scan+fill | 6 tile raster | 7 tile quads | 8 shade | 9 device->host copy
-    static constexpr int EVENT_RING = 128, N_MARKS = 10;
-    hipEvent_t ev_ring[EVENT_RING][N_MARKS] = {};
-    hipEvent_t *ev = ev_ring[0];
-    uint64_t frames_enqueued = 0;
-    bool events_ok = false;
-
-    mr_frame_desc last_frame = {};
-    int last_n_tiles = 0, bins_zeroed_for = 0;
-    bool have_frame = false, stats_reduced = false;
+    // ---- frame slots, one per stream that has rendered this scene
+    std::vector<std::unique_ptr<FrameSlot>> slots;
+    FrameSlot *last = nullptr;               // slot of the most recently enqueued frame
     mr_stats stats = {};
     int n_silhouette = 0;
 };
@@ -164,6 +195,7 @@ void build_edge_table(mr_scene *sc)
 int commit(mr_scene *sc)
 {
     if (!sc->dirty) return MR_OK;
+    HIP_TRY(hipDeviceSynchronize());          // no frame may still be reading the old arrays
     build_edge_table(sc);
     int rc;
     if ((rc = upload(sc->d_verts, sc->verts, g_stream))) return rc;
@@ -178,6 +210,17 @@ int commit(mr_scene *sc)
     HIP_TRY(hipStreamSynchronize(g_stream));
     sc->dirty = false;
     return MR_OK;
+}
+
+FrameSlot *slot_for(mr_scene *sc, hipStream_t stream)
+{
+    for (auto &s : sc->slots)
+        if (s->stream == stream) return s.get();
+    if ((int)sc->slots.size() >= MAX_SLOTS) return nullptr;
+    sc->slots.emplace_back(new (std::nothrow) FrameSlot());
+    if (!sc->slots.back()) { sc->slots.pop_back(); return nullptr; }
+    sc->slots.back()->stream = stream;
+    return sc->slots.back().get();
 }
 
 int validate_frame(const mr_frame_desc *fr)
@@ -229,162 +272,162 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
 
 inline unsigned blocks_for(long long n, int per_block) { return (unsigned)std::max<long long>(1, (n + per_block - 1) / per_block); }
 
-// Enqueues one frame on `stream`.  d_out receives the uint8 band.
-int enqueue_frame(mr_scene *sc, const mr_frame_desc *fr, uint8_t *d_out, hipStream_t stream)
+// Enqueues one frame on the slot's stream.  d_out receives the uint8 band.
+int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t *d_out)
 {
     using namespace mr;
     int rc = commit(sc);
     if (rc) return rc;
+    hipStream_t stream = fs->stream;
     const FrameConst fc = make_const(sc, fr);
     const size_t npx = (size_t)fc.width * fc.height;
     const int n_tiles = fc.tiles_x * fc.tiles_y;
     const bool shadows = (fc.flags & MR_FRAME_SHADOWS) != 0;
     const size_t nF = (size_t)std::max(fc.n_faces, 1), nV = (size_t)std::max(fc.n_vertices, 1);
 
-    if (sc->quad_cap == 0) sc->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
-    if (sc->item_cap == 0) sc->item_cap = (uint32_t)std::max<size_t>(4 * nF + 8 * (size_t)n_tiles, 1u << 22);
-    if (sc->work_cap == 0) sc->work_cap = 1u << 18;
-    if (sc->quad_work_cap == 0) sc->quad_work_cap = (uint32_t)n_tiles + (1u << 16);
+    if (fs->quad_cap == 0) fs->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
+    if (fs->item_cap == 0) fs->item_cap = (uint32_t)std::max<size_t>(4 * nF + 8 * (size_t)n_tiles, 1u << 22);
+    if (fs->work_cap == 0) fs->work_cap = 1u << 18;
+    if (fs->quad_work_cap == 0) fs->quad_work_cap = (uint32_t)n_tiles + (1u << 16);
 
-    HIP_TRY(sc->d_vout.ensure(nV * sizeof(VertexOut)));
-    HIP_TRY(sc->d_tris.ensure(nF * sizeof(TriRec)));
-    HIP_TRY(sc->d_clips.ensure(nF * sizeof(TriClip)));
-    HIP_TRY(sc->d_status.ensure(nF));
-    HIP_TRY(sc->d_lit.ensure(nF));
-    HIP_TRY(sc->d_valid.ensure(nF * sizeof(uint32_t)));
-    HIP_TRY(sc->d_quads.ensure((size_t)sc->quad_cap * sizeof(QuadRec)));
-    HIP_TRY(sc->d_sil.ensure((size_t)sc->quad_cap * 3 * sizeof(int32_t)));
-    HIP_TRY(sc->d_counters.ensure(sizeof(Counters)));
-    HIP_TRY(sc->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
-    HIP_TRY(sc->d_bin_offset.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
-    HIP_TRY(sc->d_items.ensure((size_t)sc->item_cap * 4));
-    HIP_TRY(sc->d_work.ensure((size_t)sc->work_cap * sizeof(uint2)));
-    HIP_TRY(sc->d_quad_work.ensure((size_t)sc->quad_work_cap * sizeof(uint4)));
-    HIP_TRY(sc->d_tile_stats.ensure((size_t)n_tiles * TILE_REC * 4));
-    HIP_TRY(sc->d_z.ensure(npx * sizeof(double)));
-    HIP_TRY(sc->d_winner.ensure(npx * sizeof(int32_t)));
-    HIP_TRY(sc->d_stencil.ensure(npx * sizeof(int32_t)));
-    if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(sc->d_frame.ensure(npx * 3 * sizeof(float)));
-    if (!sc->events_ok) {
-        for (auto &set : sc->ev_ring) for (auto &e : set) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipHostMalloc((void **)&sc->h_counters, sizeof(Counters), hipHostMallocDefault));
-        sc->events_ok = true;
+    HIP_TRY(fs->d_vout.ensure(nV * sizeof(VertexOut)));
+    HIP_TRY(fs->d_tris.ensure(nF * sizeof(TriRec)));
+    HIP_TRY(fs->d_clips.ensure(nF * sizeof(TriClip)));
+    HIP_TRY(fs->d_status.ensure(nF));
+    HIP_TRY(fs->d_lit.ensure(nF));
+    HIP_TRY(fs->d_valid.ensure(nF * sizeof(uint32_t)));
+    HIP_TRY(fs->d_quads.ensure((size_t)fs->quad_cap * sizeof(QuadRec)));
+    HIP_TRY(fs->d_sil.ensure((size_t)fs->quad_cap * 3 * sizeof(int32_t)));
+    HIP_TRY(fs->d_counters.ensure(sizeof(Counters)));
+    HIP_TRY(fs->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
+    HIP_TRY(fs->d_bin_offset.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
+    HIP_TRY(fs->d_items.ensure((size_t)fs->item_cap * 4));
+    HIP_TRY(fs->d_work.ensure((size_t)fs->work_cap * sizeof(uint2)));
+    HIP_TRY(fs->d_quad_work.ensure((size_t)fs->quad_work_cap * sizeof(uint4)));
+    HIP_TRY(fs->d_tile_stats.ensure((size_t)n_tiles * TILE_REC * 4));
+    HIP_TRY(fs->d_z.ensure(npx * sizeof(double)));
+    HIP_TRY(fs->d_winner.ensure(npx * sizeof(int32_t)));
+    HIP_TRY(fs->d_stencil.ensure(npx * sizeof(int32_t)));
+    if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(fs->d_frame.ensure(npx * 3 * sizeof(float)));
+    if (!fs->events_ok) {
+        for (auto &set : fs->ev_ring) for (auto &e : set) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipHostMalloc((void **)&fs->h_counters, sizeof(Counters), hipHostMallocDefault));
+        fs->events_ok = true;
     }
-    sc->ev = sc->ev_ring[sc->frames_enqueued % mr_scene::EVENT_RING];
+    fs->ev = fs->ev_ring[fs->frames_enqueued % EVENT_RING];
 
-    Counters *ctr = sc->d_counters.as<Counters>();
-    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the visibility kernels
+    Counters *ctr = fs->d_counters.as<Counters>();
+    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the visibility / shading kernels
     const bool all_marks = !(fc.flags & MR_FRAME_LIGHT_TIMING);
-    HIP_TRY(hipEventRecord(sc->ev[0], stream));
+    HIP_TRY(hipEventRecord(fs->ev[0], stream));
     // The bin cursors are left zeroed by k_tile_raster and the frame counters are cleared by
     // k_vertex, so a steady-state frame issues no memset; only a new tile grid needs one.
-    if (sc->bins_zeroed_for != BIN_CLASSES * n_tiles + 1) {
-        HIP_TRY(hipMemsetAsync(sc->d_bin_count.p, 0, sc->d_bin_count.cap, stream));
-        sc->bins_zeroed_for = BIN_CLASSES * n_tiles + 1;
+    if (fs->bins_zeroed_for != BIN_CLASSES * n_tiles + 1) {
+        HIP_TRY(hipMemsetAsync(fs->d_bin_count.p, 0, fs->d_bin_count.cap, stream));
+        fs->bins_zeroed_for = BIN_CLASSES * n_tiles + 1;
     }
 
     // ---- geometry
     hipLaunchKernelGGL(k_vertex, dim3(blocks_for(fc.n_vertices, 256)), dim3(256), 0, stream, fc,
-                       sc->d_verts.as<double>(), sc->d_vout.as<VertexOut>(), ctr);
-    if (fc.n_faces > 0) {
+                       sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), ctr);
+    if (fc.n_faces > 0)
         hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
-                           sc->d_vout.as<VertexOut>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
-                           sc->d_status.as<uint8_t>(), sc->d_lit.as<uint8_t>(), sc->d_valid.as<uint32_t>(), ctr);
-        if (all_marks) HIP_TRY(hipEventRecord(sc->ev[1], stream));
+                           fs->d_vout.as<VertexOut>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
+                           fs->d_status.as<uint8_t>(), fs->d_lit.as<uint8_t>(), fs->d_valid.as<uint32_t>(), ctr);
+    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
+    if (fc.n_faces > 0)
         hipLaunchKernelGGL(k_tri_count, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream,
-                           fc, sc->d_valid.as<uint32_t>(), sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(),
-                           sc->d_status.as<uint8_t>(), ctr);
-    } else {
-        if (all_marks) HIP_TRY(hipEventRecord(sc->ev[1], stream));
-    }
-    if (all_marks) HIP_TRY(hipEventRecord(sc->ev[2], stream));
+                           fc, fs->d_valid.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
+                           fs->d_status.as<uint8_t>(), ctr);
+    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
     if (shadows && fc.n_edges > 0) {
         hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 256)), dim3(256), 0, stream, fc,
                            sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
-                           sc->d_lit.as<uint8_t>(), sc->d_sil.as<int32_t>(), sc->quad_cap, ctr);
-        hipLaunchKernelGGL(k_quad_setup, dim3((unsigned)std::min<long long>(1024, blocks_for(std::min<long long>(fc.n_edges, sc->quad_cap) * QS_LANES, 64))), dim3(64),
-                           0, stream, fc, sc->d_sil.as<int32_t>(), sc->d_verts.as<double>(), sc->d_quads.as<QuadRec>(),
-                           sc->quad_cap, ctr);
+                           fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap, ctr);
+        const long long max_sil = std::min<long long>(fc.n_edges, fs->quad_cap);
+        hipLaunchKernelGGL(k_quad_setup, dim3((unsigned)std::min<long long>(1024, blocks_for(max_sil * QS_LANES, 64))),
+                           dim3(64), 0, stream, fc, fs->d_sil.as<int32_t>(), sc->d_verts.as<double>(),
+                           fs->d_quads.as<QuadRec>(), fs->quad_cap, ctr);
     }
-    if (all_marks) HIP_TRY(hipEventRecord(sc->ev[3], stream));
+    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[3], stream));
 
     // ---- binning: classify + count, large-primitive count, scan, fill, large-primitive fill
     BinArgs ba;
-    ba.tris = sc->d_tris.as<TriRec>(); ba.valid_list = sc->d_valid.as<uint32_t>();
-    ba.status = sc->d_status.as<uint8_t>(); ba.quads = sc->d_quads.as<QuadRec>();
-    ba.ctr = ctr; ba.quad_cap = sc->quad_cap;
-    ba.bin_count = sc->d_bin_count.as<uint32_t>(); ba.bin_offset = sc->d_bin_offset.as<uint32_t>();
-    ba.items = sc->d_items.as<uint32_t>(); ba.item_cap = sc->item_cap;
-    ba.work = sc->d_work.as<uint2>(); ba.work_cap = sc->work_cap;
-    ba.quad_work = sc->d_quad_work.as<uint4>(); ba.quad_work_cap = sc->quad_work_cap;
-    const long long n_prims_max = (long long)fc.n_faces + (shadows ? std::min<long long>(fc.n_edges, sc->quad_cap) : 0);
+    ba.tris = fs->d_tris.as<TriRec>(); ba.valid_list = fs->d_valid.as<uint32_t>();
+    ba.status = fs->d_status.as<uint8_t>(); ba.quads = fs->d_quads.as<QuadRec>();
+    ba.ctr = ctr; ba.quad_cap = fs->quad_cap;
+    ba.bin_count = fs->d_bin_count.as<uint32_t>(); ba.bin_offset = fs->d_bin_offset.as<uint32_t>();
+    ba.items = fs->d_items.as<uint32_t>(); ba.item_cap = fs->item_cap;
+    ba.work = fs->d_work.as<uint2>(); ba.work_cap = fs->work_cap;
+    ba.quad_work = fs->d_quad_work.as<uint4>(); ba.quad_work_cap = fs->quad_work_cap;
+    const long long n_prims_max = (long long)fc.n_faces + (shadows ? std::min<long long>(fc.n_edges, fs->quad_cap) : 0);
     const unsigned classify_blocks = blocks_for(std::max<long long>(n_prims_max, n_tiles), 256);
     const unsigned large_blocks = 1024;      // grid-stride over the work items, 4 wavefronts per block
     hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
     hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
-    if (all_marks) HIP_TRY(hipEventRecord(sc->ev[4], stream));
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, sc->d_bin_count.as<uint32_t>(),
-                       sc->d_bin_offset.as<uint32_t>(), n_tiles, sc->item_cap, ctr);
+    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[4], stream));
+    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, fs->d_bin_count.as<uint32_t>(),
+                       fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr);
     hipLaunchKernelGGL((k_bin_classify<true>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
     hipLaunchKernelGGL((k_bin_large<true>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
-    HIP_TRY(hipEventRecord(sc->ev[5], stream));
+    HIP_TRY(hipEventRecord(fs->ev[5], stream));
 
-    // ---- visibility: coverage, z, stencil
-    const unsigned raster_blocks = (unsigned)n_tiles;
-    hipLaunchKernelGGL(k_tile_raster, dim3(raster_blocks), dim3(TILE_PX), 0, stream, fc,
-                       sc->d_tris.as<TriRec>(), sc->d_clips.as<TriClip>(), sc->d_quads.as<QuadRec>(),
-                       sc->d_bin_offset.as<uint32_t>(), sc->d_items.as<uint32_t>(), sc->item_cap,
-                       sc->d_bin_count.as<uint32_t>(), sc->d_z.as<double>(), sc->d_winner.as<int32_t>(),
-                       sc->d_stencil.as<int32_t>(), sc->d_tile_stats.as<uint32_t>());
-    HIP_TRY(hipEventRecord(sc->ev[6], stream));
+    // ---- visibility: coverage, z, winner; then the shadow volumes' stencil counts
+    hipLaunchKernelGGL(k_tile_raster, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc,
+                       fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(), fs->d_quads.as<QuadRec>(),
+                       fs->d_bin_offset.as<uint32_t>(), fs->d_items.as<uint32_t>(), fs->item_cap,
+                       fs->d_bin_count.as<uint32_t>(), fs->d_z.as<double>(), fs->d_winner.as<int32_t>(),
+                       fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>());
+    HIP_TRY(hipEventRecord(fs->ev[6], stream));
     if (shadows)
-        hipLaunchKernelGGL(k_tile_quads, dim3(2048), dim3(TILE_PX), 0, stream, fc, sc->d_quads.as<QuadRec>(),
-                           sc->d_quad_work.as<uint4>(), sc->quad_work_cap, sc->d_items.as<uint32_t>(), sc->item_cap,
-                           sc->d_z.as<double>(), sc->d_stencil.as<int32_t>(), sc->d_tile_stats.as<uint32_t>(), ctr);
-    HIP_TRY(hipEventRecord(sc->ev[7], stream));
+        hipLaunchKernelGGL(k_tile_quads, dim3(2048), dim3(TILE_PX), 0, stream, fc, fs->d_quads.as<QuadRec>(),
+                           fs->d_quad_work.as<uint4>(), fs->quad_work_cap, fs->d_items.as<uint32_t>(), fs->item_cap,
+                           fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>(), ctr);
+    HIP_TRY(hipEventRecord(fs->ev[7], stream));
 
     // ---- deferred shading + finalise
     ShadeArgs sa;
-    sa.tris = sc->d_tris.as<TriRec>(); sa.clips = sc->d_clips.as<TriClip>(); sa.faces = sc->d_faces.as<int32_t>();
+    sa.tris = fs->d_tris.as<TriRec>(); sa.clips = fs->d_clips.as<TriClip>(); sa.faces = sc->d_faces.as<int32_t>();
     sa.face_flags = sc->d_face_flags.as<uint8_t>(); sa.verts = sc->d_verts.as<double>();
     sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
     sa.materials = sc->d_materials.as<Material>(); sa.textures = sc->d_textures.as<Texture>();
-    sa.winner = sc->d_winner.as<int32_t>(); sa.stencil = sc->d_stencil.as<int32_t>();
-    sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? sc->d_frame.as<float>() : nullptr;
+    sa.winner = fs->d_winner.as<int32_t>(); sa.stencil = fs->d_stencil.as<int32_t>();
+    sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
     sa.out = d_out;
     const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(band_px, 256)), dim3(256), 0, stream, fc, sa);
-    HIP_TRY(hipEventRecord(sc->ev[8], stream));
+    HIP_TRY(hipEventRecord(fs->ev[8], stream));
     HIP_TRY(hipGetLastError());
-    sc->last_frame = *fr;
-    sc->last_n_tiles = n_tiles;
-    sc->have_frame = true;
-    sc->stats_reduced = false;
-    sc->frames_enqueued += 1;
+    fs->last_frame = *fr;
+    fs->last_n_tiles = n_tiles;
+    fs->have_frame = true;
+    fs->stats_reduced = false;
+    fs->frames_enqueued += 1;
+    sc->last = fs;
     return MR_OK;
 }
 
-// The fragment / pixel counts of a frame are left as per-tile partials by k_tile_raster; they
-// are summed and fetched only when somebody asks (mr_render, mr_get_stats), not per frame.
-int fetch_counters(mr_scene *sc, hipStream_t stream)
+// The fragment / pixel counts of a frame are left as per-tile partials by the visibility
+// kernels; they are summed and fetched only when somebody asks (mr_render, mr_get_stats).
+int fetch_counters(mr_scene *sc, FrameSlot *fs)
 {
     using namespace mr;
-    Counters *ctr = sc->d_counters.as<Counters>();
-    if (!sc->stats_reduced) {
-        const FrameConst fc = make_const(sc, &sc->last_frame);
-        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, stream, fc, sc->d_tile_stats.as<uint32_t>(),
-                           sc->last_n_tiles, sc->d_winner.as<int32_t>(), sc->d_stencil.as<int32_t>(), ctr);
-        sc->stats_reduced = true;
+    Counters *ctr = fs->d_counters.as<Counters>();
+    if (!fs->stats_reduced) {
+        const FrameConst fc = make_const(sc, &fs->last_frame);
+        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, fs->stream, fc, fs->d_tile_stats.as<uint32_t>(),
+                           fs->last_n_tiles, fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(), ctr);
+        fs->stats_reduced = true;
     }
-    HIP_TRY(hipMemcpyAsync(sc->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(fs->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, fs->stream));
     return MR_OK;
 }
 
 // After the stream has drained: turn counters + events into mr_stats; grow work lists on overflow.
-int collect(mr_scene *sc, bool with_copy)
+int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
 {
-    const mr::Counters &c = *sc->h_counters;
+    const mr::Counters &c = *fs->h_counters;
     mr_stats &s = sc->stats;
     s.frag_tri = (int64_t)c.frag_tri; s.frag_quad = (int64_t)c.frag_quad;
     s.covered_px = (int64_t)c.covered_px; s.lit_px = (int64_t)c.lit_px;
@@ -394,32 +437,39 @@ int collect(mr_scene *sc, bool with_copy)
     s.tri_bin_entries = c.tri_bin_total; s.quad_bin_entries = c.quad_bin_total;
     sc->n_silhouette = (int)c.n_quads;
     float ms = 0;
-    auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, sc->ev[a], sc->ev[b]); return ms; };
-    const bool light = (sc->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
+    auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, fs->ev[a], fs->ev[b]); return ms; };
+    const bool light = (fs->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
     s.gpu_ms_geometry = light ? 0.f : span(0, 3); s.gpu_ms_binning = light ? 0.f : span(3, 5);
     s.gpu_ms_raster = span(5, 7); s.gpu_ms_shade = span(7, 8);
     s.gpu_ms_copy = with_copy ? span(8, 9) : 0.f;
     s.gpu_ms_total = span(0, with_copy ? 9 : 8);
+    bool grown = false;
     if (c.overflow) {
         const uint32_t entries = c.tri_bin_total + c.quad_bin_total;
-        if (c.overflow & 1u) { sc->item_cap = entries + entries / 2 + 1024; }
-        if (c.overflow & 2u) { sc->work_cap = c.n_work + c.n_work / 2 + 1024; }
-        if (c.overflow & 8u) { sc->quad_work_cap = c.n_quad_work + c.n_quad_work / 2 + 1024; }
-        if (c.overflow & 4u) { sc->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, sc->quad_cap * 2); }
-        if (c.n_quads > sc->quad_cap) sc->quad_cap = c.n_quads + c.n_quads / 2 + 64;
-        return MR_E_OVERFLOW;
+        if (c.overflow & 1u) fs->item_cap = entries + entries / 2 + 1024;
+        if (c.overflow & 2u) fs->work_cap = c.n_work + c.n_work / 2 + 1024;
+        if (c.overflow & 4u) fs->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, fs->quad_cap * 2);
+        if (c.overflow & 8u) fs->quad_work_cap = c.n_quad_work + c.n_quad_work / 2 + 1024;
+        grown = true;
     }
-    if (c.n_quads > sc->quad_cap) { sc->quad_cap = c.n_quads + c.n_quads / 2 + 64; return MR_E_OVERFLOW; }
-    return MR_OK;
+    if (c.n_quads > fs->quad_cap) { fs->quad_cap = c.n_quads + c.n_quads / 2 + 64; grown = true; }
+    return grown ? MR_E_OVERFLOW : MR_OK;
 }
 
 template <class T>
-int read_back(mr_scene *sc, const DevBuf &buf, T *out, size_t count, const char *what)
+int read_back(const DevBuf &buf, T *out, size_t count, const char *what)
 {
-    if (!sc || !out) return fail(MR_E_INVALID, "NULL argument");
-    if (!sc->have_frame || !buf.p) return fail(MR_E_INVALID, std::string(what) + ": nothing rendered yet");
+    if (!out) return fail(MR_E_INVALID, "NULL argument");
+    if (!buf.p) return fail(MR_E_INVALID, std::string(what) + ": nothing rendered yet");
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, buf.p, count * sizeof(T), hipMemcpyDeviceToHost));
     return MR_OK;
+}
+
+FrameSlot *last_slot(mr_scene *sc)
+{
+    if (!sc || !sc->last || !sc->last->have_frame) { fail(MR_E_INVALID, "nothing rendered yet"); return nullptr; }
+    return sc->last;
 }
 
 }  // namespace
@@ -471,29 +521,25 @@ mr_scene *mr_scene_create(void)
 int mr_scene_clear(mr_scene *sc)
 {
     if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    if (g_initialised) (void)hipDeviceSynchronize();
     for (void *p : sc->texture_allocs) (void)hipFree(p);
     sc->texture_allocs.clear(); sc->textures.clear();
     sc->verts.clear(); sc->uv.clear(); sc->normals.clear(); sc->faces.clear(); sc->face_flags.clear();
     sc->materials.clear(); sc->models.clear(); sc->edge_offset.clear(); sc->edge_inc.clear();
-    sc->dirty = true; sc->have_frame = false; sc->bins_zeroed_for = 0;
-    sc->item_cap = sc->work_cap = sc->quad_cap = sc->quad_work_cap = 0;
+    sc->dirty = true;
+    sc->last = nullptr;
+    for (auto &fs : sc->slots) fs->reset_caps();
     return MR_OK;
 }
 
 void mr_scene_destroy(mr_scene *sc)
 {
     if (!sc) return;
-    if (g_initialised) (void)hipStreamSynchronize(g_stream);
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
-                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_vout, &sc->d_tris, &sc->d_clips,
-                       &sc->d_status, &sc->d_lit, &sc->d_valid, &sc->d_quads, &sc->d_sil, &sc->d_counters,
-                       &sc->d_bin_count, &sc->d_bin_offset, &sc->d_items, &sc->d_work, &sc->d_quad_work, &sc->d_tile_stats, &sc->d_z, &sc->d_winner, &sc->d_stencil, &sc->d_frame, &sc->d_out };
+                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc };
     for (DevBuf *b : bufs) b->release();
-    if (sc->events_ok) {
-        for (auto &set : sc->ev_ring) for (auto &e : set) (void)hipEventDestroy(e);
-        (void)hipHostFree(sc->h_counters);
-    }
+    for (auto &fs : sc->slots) fs->release();
     delete sc;
 }
 
@@ -545,6 +591,7 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
         if (m->normals && (c[2] < 0 || c[2] >= m->n_normals)) return fail(MR_E_INVALID, "normal index out of range");
         if (c[3] < 0 || c[3] >= m->n_materials) return fail(MR_E_INVALID, "material index out of range");
     }
+    if (g_initialised) (void)hipDeviceSynchronize();     // frames in flight still use the old scene
     sc->verts.insert(sc->verts.end(), m->vertices, m->vertices + (size_t)m->n_vertices * 4);
     if (m->uv) sc->uv.insert(sc->uv.end(), m->uv, m->uv + (size_t)m->n_uv * 3);
     if (m->normals) sc->normals.insert(sc->normals.end(), m->normals, m->normals + (size_t)m->n_normals * 3);
@@ -569,7 +616,8 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
     sc->face_flags.insert(sc->face_flags.end(), (size_t)m->n_faces, ff);
     sc->models.push_back(mi);
     sc->dirty = true;
-    sc->item_cap = sc->work_cap = sc->quad_cap = sc->quad_work_cap = 0;
+    sc->last = nullptr;
+    for (auto &fs : sc->slots) fs->reset_caps();
     return (int)sc->models.size() - 1;
 }
 
@@ -579,15 +627,17 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     int rc = validate_frame(fr);
     if (rc) return rc;
     if ((rc = ensure_init())) return rc;
+    FrameSlot *fs = slot_for(sc, g_stream);
+    if (!fs) return fail(MR_E_DEVICE, "out of frame slots");
     const size_t band_bytes = (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        HIP_TRY(sc->d_out.ensure(band_bytes));
-        if ((rc = enqueue_frame(sc, fr, sc->d_out.as<uint8_t>(), g_stream))) return rc;
-        if ((rc = fetch_counters(sc, g_stream))) return rc;
-        HIP_TRY(hipMemcpyAsync(out_rgb, sc->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipEventRecord(sc->ev[9], g_stream));
+        HIP_TRY(fs->d_out.ensure(band_bytes));
+        if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
+        if ((rc = fetch_counters(sc, fs))) return rc;
+        HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipEventRecord(fs->ev[9], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
-        rc = collect(sc, true);
+        rc = collect(sc, fs, true);
         if (rc == MR_OK) {
             if (stats) *stats = sc->stats;
             return MR_OK;
@@ -603,99 +653,127 @@ int mr_render_device(mr_scene *sc, const mr_frame_desc *fr, void *d_out_rgb, voi
     int rc = validate_frame(fr);
     if (rc) return rc;
     if ((rc = ensure_init())) return rc;
-    return enqueue_frame(sc, fr, static_cast<uint8_t *>(d_out_rgb), stream ? (hipStream_t)stream : g_stream);
+    FrameSlot *fs = slot_for(sc, stream ? (hipStream_t)stream : g_stream);
+    if (!fs) return fail(MR_E_INVALID, "a scene can be rendered from at most 8 different streams");
+    return enqueue_frame(sc, fs, fr, static_cast<uint8_t *>(d_out_rgb));
 }
 
 int mr_get_stats(mr_scene *sc, mr_stats *stats)
 {
     if (!sc || !stats) return fail(MR_E_INVALID, "NULL argument");
-    if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
     HIP_TRY(hipDeviceSynchronize());
-    int rc = fetch_counters(sc, g_stream);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    rc = collect(sc, false);
+    // a frame on any stream may have overflowed its lists: grow them all before reporting
+    bool overflowed = false;
+    for (auto &s : sc->slots) {
+        if (!s->have_frame) continue;
+        int rc = fetch_counters(sc, s.get());
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (collect(sc, s.get(), false) == MR_E_OVERFLOW) overflowed = true;
+    }
+    (void)collect(sc, fs, false);               // report the most recent frame
     *stats = sc->stats;
-    if (rc == MR_E_OVERFLOW)
-        return fail(MR_E_OVERFLOW, "the last frame overflowed a work list (now grown): render it again");
-    return rc;
+    if (overflowed)
+        return fail(MR_E_OVERFLOW, "a frame overflowed a work list (now grown): render it again");
+    return MR_OK;
 }
 
 int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
 {
     if (!sc || !out_ms || cap < MR_N_KERNEL_TIMES) return fail(MR_E_INVALID, "need room for MR_N_KERNEL_TIMES floats");
-    if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    if (!last_slot(sc)) return MR_E_INVALID;
     HIP_TRY(hipDeviceSynchronize());
-    const uint64_t have = std::min<uint64_t>(sc->frames_enqueued, mr_scene::EVENT_RING);
-    const uint64_t n = std::min<uint64_t>(have, n_frames > 0 ? (uint64_t)n_frames : 1);
     double acc[MR_N_KERNEL_TIMES] = {};
-    const bool light = (sc->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        hipEvent_t *ev = sc->ev_ring[(sc->frames_enqueued - 1 - i) % mr_scene::EVENT_RING];
-        float ms;
-        for (int k = light ? 5 : 0; k < 8; ++k) {
-            ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
-            acc[k] += ms;
+    uint64_t used = 0;
+    int active = 0;
+    for (auto &s : sc->slots) active += s->have_frame ? 1 : 0;
+    const uint64_t per_slot = std::max<uint64_t>(1, ((uint64_t)std::max(n_frames, 1) + active - 1) / std::max(active, 1));
+    for (auto &s : sc->slots) {
+        if (!s->have_frame) continue;
+        const bool light = (s->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
+        const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(s->frames_enqueued, EVENT_RING), per_slot);
+        for (uint64_t i = 0; i < n; ++i) {
+            hipEvent_t *ev = s->ev_ring[(s->frames_enqueued - 1 - i) % EVENT_RING];
+            float ms;
+            for (int k = light ? 5 : 0; k < 8; ++k) {
+                ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+                acc[k] += ms;
+            }
+            ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[8]);
+            acc[8] += ms;
         }
-        ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[8]);
-        acc[8] += ms;
+        used += n;
     }
-    for (int k = 0; k < MR_N_KERNEL_TIMES; ++k) out_ms[k] = (float)(acc[k] / (double)n);
-    return (int)n;
+    for (int k = 0; k < MR_N_KERNEL_TIMES; ++k) out_ms[k] = used ? (float)(acc[k] / (double)used) : 0.f;
+    return (int)used;
 }
 
 int mr_read_z(mr_scene *sc, double *out)
 {
-    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    return read_back(sc, sc->d_z, out, (size_t)sc->last_frame.width * sc->last_frame.height, "z");
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    return read_back(fs->d_z, out, (size_t)fs->last_frame.width * fs->last_frame.height, "z");
 }
+
 int mr_read_stencil(mr_scene *sc, int16_t *out)
 {
-    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    const size_t n = (size_t)sc->last_frame.width * sc->last_frame.height;
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    const size_t n = (size_t)fs->last_frame.width * fs->last_frame.height;
     std::vector<int32_t> wide(n);           // the device accumulates in 32 bits; the reference's buffer is int16
-    int rc = read_back(sc, sc->d_stencil, wide.data(), n, "stencil");
+    int rc = read_back(fs->d_stencil, wide.data(), n, "stencil");
     if (rc) return rc;
+    if (!out) return fail(MR_E_INVALID, "NULL argument");
     for (size_t i = 0; i < n; ++i) out[i] = (int16_t)wide[i];
     return MR_OK;
 }
+
 int mr_read_winner(mr_scene *sc, int32_t *out)
 {
-    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    return read_back(sc, sc->d_winner, out, (size_t)sc->last_frame.width * sc->last_frame.height, "winner");
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    return read_back(fs->d_winner, out, (size_t)fs->last_frame.width * fs->last_frame.height, "winner");
 }
+
 int mr_read_frame_f32(mr_scene *sc, float *out)
 {
-    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    if (!(sc->last_frame.flags & MR_FRAME_KEEP_FLOAT))
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    if (!(fs->last_frame.flags & MR_FRAME_KEEP_FLOAT))
         return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_KEEP_FLOAT");
-    return read_back(sc, sc->d_frame, out, (size_t)sc->last_frame.width * sc->last_frame.height * 3, "frame");
+    return read_back(fs->d_frame, out, (size_t)fs->last_frame.width * fs->last_frame.height * 3, "frame");
 }
+
 int mr_read_face_status(mr_scene *sc, uint8_t *out)
 {
-    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    return fail(MR_E_UNSUPPORTED, "per-face status of the lit pass is not implemented yet");
+    if (!last_slot(sc)) return MR_E_INVALID;
     (void)out;
+    return fail(MR_E_UNSUPPORTED, "per-face status of the lit pass is not implemented yet");
 }
 
 int mr_debug_read_tile_records(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
 {
-    if (!sc || !out) return fail(MR_E_INVALID, "NULL argument");
-    if (!sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
-    const int n = std::min(sc->last_n_tiles, cap_tiles);
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    if (!out) return fail(MR_E_INVALID, "NULL argument");
+    const int n = std::min(fs->last_n_tiles, cap_tiles);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, sc->d_tile_stats.p, (size_t)n * mr::TILE_REC * 4, hipMemcpyDeviceToHost));
-    return sc->last_n_tiles;
+    if (n > 0) HIP_TRY(hipMemcpy(out, fs->d_tile_stats.p, (size_t)n * mr::TILE_REC * 4, hipMemcpyDeviceToHost));
+    return fs->last_n_tiles;
 }
 
 int mr_read_silhouette(mr_scene *sc, int32_t *out, int32_t cap)
 {
-    if (!sc || !sc->have_frame) return fail(MR_E_INVALID, "nothing rendered yet");
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
     const int n = sc->n_silhouette;
-    const int take = std::min(std::min(n, cap), (int)sc->quad_cap);
+    const int take = std::min(std::min(n, cap), (int)fs->quad_cap);
     if (take > 0 && out) {
         std::vector<int32_t> raw((size_t)take * 3);
-        HIP_TRY(hipMemcpy(raw.data(), sc->d_sil.p, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(raw.data(), fs->d_sil.p, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (int i = 0; i < take; ++i) {
             const int face = raw[i * 3];
             int model = 0;

@@ -63,6 +63,15 @@ __device__ __forceinline__ void normalize3(const double a[3], double o[3])
     o[0] = a[0] / l; o[1] = a[1] / l; o[2] = a[2] / l;
 }
 
+// 1/x to ~1e-16 relative (v_rcp_f64 seed, ~2^-23, plus two Newton steps); NOT correctly rounded:
+// only for colour and for pre-tests whose close calls are re-done exactly.
+__device__ __forceinline__ double approx_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double linearize_z(const FrameConst &fc, double d)
 {
     return fc.two_nf / (fc.f_plus_n - d * fc.f_minus_n);

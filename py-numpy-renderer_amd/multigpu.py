@@ -39,26 +39,45 @@ def all_gather_frame(part, frame=None, group=None):
 
 
 class BandRenderer:
-    """Per-rank driver: render this rank's band into HBM, then all-gather the frame."""
+    """Per-rank driver: render this rank's band into HBM, then all-gather the frame.
 
-    def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False):
+    ``frames_in_flight`` > 1 renders successive frames on different HIP streams (each with
+    its own output buffers and its own work buffers inside the library), so the short,
+    latency-bound stages of one frame overlap with the next frame's: throughput mode.  With 1
+    every frame runs alone on one stream: latency mode.
+    """
+
+    def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False, frames_in_flight=1):
         height, width = (int(v) for v in scene.resolution)
         self.rank, self.world = rank, world
         self.band = row_band(height, rank, world)
         self.backend = scene._backend()
-        self.stream = torch.cuda.Stream()
-        self.frame = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
         rows = self.band[1] - self.band[0]
-        self.part = self.frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
-        with torch.cuda.stream(self.stream):
-            self.desc = self.backend.render_device(scene, self.part.data_ptr(), self.stream.cuda_stream,
-                                                   shadows=shadows, row_band=self.band, light_timing=light_timing)
-        self.stream.synchronize()
+        self.lanes = []
+        self.count = 0
+        self.desc = None
+        for _ in range(max(1, int(frames_in_flight))):
+            stream = torch.cuda.Stream()
+            frame = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
+            part = frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
+            with torch.cuda.stream(stream):
+                self.desc = self.backend.render_device(scene, part.data_ptr(), stream.cuda_stream, shadows=shadows,
+                                                       row_band=self.band, light_timing=light_timing)
+            stream.synchronize()
+            self.lanes.append((stream, frame, part))
+        self.frame = self.lanes[0][1]
 
     def step(self):
-        """Enqueue one frame (no host synchronisation)."""
-        with torch.cuda.stream(self.stream):
-            self.backend.enqueue(self.desc, self.part.data_ptr(), self.stream.cuda_stream)
+        """Enqueue one frame (no host synchronisation); returns the tensor it will land in."""
+        stream, frame, part = self.lanes[self.count % len(self.lanes)]
+        self.count += 1
+        with torch.cuda.stream(stream):
+            self.backend.enqueue(self.desc, part.data_ptr(), stream.cuda_stream)
             if self.world > 1:
-                all_gather_frame(self.part, self.frame)
-        return self.frame
+                all_gather_frame(part, frame)
+        self.frame = frame
+        return frame
+
+    def synchronize(self):
+        for stream, _, _ in self.lanes:
+            stream.synchronize()
