@@ -3,7 +3,8 @@ from .constants import PROJECTION_TYPE, SUBSYSTEM, SYSTEM
 from .core import Camera, Light, Model, Scene, TextureMaps
 from .lightning import Lightning
 from .materials import Material
+from .triangular import Errors
 from .transformation import rotate_xyz, scale, translation
 
-__all__ = ["Camera", "Light", "Model", "Scene", "TextureMaps", "Material", "Lightning",
+__all__ = ["Errors", "Camera", "Light", "Model", "Scene", "TextureMaps", "Material", "Lightning",
            "PROJECTION_TYPE", "SUBSYSTEM", "SYSTEM", "scale", "translation", "rotate_xyz"]

@@ -114,12 +114,12 @@ def _check(rc, what):
     return rc
 
 
-def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False):
+def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False):
     d = FrameDesc()
     d.width, d.height, d.system = pf.width, pf.height, pf.system
     d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
     d.flags = ((FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
-               | (FRAME_LIGHT_TIMING if light_timing else 0))
+               | (FRAME_LIGHT_TIMING if light_timing else 0) | (FRAME_FACE_STATUS if face_status else 0))
     d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
     for name in ("mvp", "viewport", "debug_mvp", "frustum_planes", "camera_pos", "light_pos", "light_dir",
                  "light_color", "light_ambient"):
@@ -191,11 +191,12 @@ class DeviceRenderer:
         self._signature = sig
 
     # -- frames ---------------------------------------------------------------------------
-    def render(self, scene, shadows=True, row_band=None, keep_float=False):
+    def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False):
         """``mr_render``: returns the uint8 band ``(rows, W, 3)`` as a NumPy array."""
         self.sync_scene(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, keep_float)
+        desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status)
+        self._n_faces = sum(len(m._faces) for m in scene.models)
         rows = desc.row_end - desc.row_begin
         out = np.empty((rows, pf.width, 3), dtype=np.uint8)
         stats = Stats()
@@ -260,6 +261,12 @@ class DeviceRenderer:
         out = np.empty((max(n, 1), 8), dtype=np.uint32)
         _check(self.lib.mr_debug_read_tile_records(self.handle, out.ctypes.data, n), "mr_debug_read_tile_records")
         return out[:n]
+
+    def read_face_status(self):
+        """One ``Errors`` value (0 = rendered) per face, models concatenated in scene order."""
+        out = np.empty(max(self._n_faces, 1), dtype=np.uint8)
+        _check(self.lib.mr_read_face_status(self.handle, out.ctypes.data), "mr_read_face_status")
+        return out[:self._n_faces]
 
     def read_silhouette(self):
         n = _check(self.lib.mr_read_silhouette(self.handle, None, 0), "mr_read_silhouette")

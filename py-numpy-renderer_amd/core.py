@@ -327,7 +327,8 @@ class Scene:
         self.skybox = skymap
         self.shadows = shadows
         self.device = device
-        self.draw_debug_frustum = True      # the reference always overlays it (core.py:638)
+        self.draw_debug_frustum = False     # the reference always overlays it (core.py:638); opt-in here
+        self.verbose = False                # the reference always prints its face histogram (core.py:634-636)
         self._renderer = None
         self.last_stats = None
 
@@ -345,11 +346,36 @@ class Scene:
         """Render one frame on the GPU and return ``uint8 (H, W, 3)`` (row 0 = top).
 
         Unlike the reference, repeated calls give the same frame: the silhouette is rebuilt
-        from scratch every frame instead of being toggled in ``model.silhouette``."""
+        from scratch every frame instead of being toggled in ``model.silhouette``.  With
+        ``scene.verbose`` (off by default) the three lines the reference prints per model after
+        its lit pass (``obj/core.py:634-636``) are reproduced from the device's per-face codes."""
         backend = self._backend()
-        out = backend.render(self, shadows=shadows, row_band=row_band)
+        report = self.verbose and row_band is None
+        overlay = self.draw_debug_frustum and row_band is None
+        out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, keep_float=overlay)
         self.last_stats = backend.last_stats
+        if report:
+            self._print_face_report(backend.read_face_status())
+        if overlay:
+            # debug aid (obj/core.py:638): drawn on the host into the device's float frame and
+            # z-buffer, then finalised with the reference's own expression (obj/core.py:640)
+            from .frustums import draw_view_frustum
+            frame, z_buffer = backend.read_frame_f32(), backend.read_z()
+            debug = self.debug_camera if self.debug_camera is not None else self.camera
+            draw_view_frustum(frame, self.camera, debug, z_buffer, self.system)
+            out = (frame[::-1] ** 0.8 * 255).astype(np.uint8)
         return out
+
+    def _print_face_report(self, status):
+        from .triangular import Errors
+        first = 0
+        for model in self.models:
+            codes = status[first:first + len(model._faces)]
+            first += len(model._faces)
+            histogram = {err: int((codes == err.value).sum()) for err in Errors}
+            print('Total faces', len(model._faces))
+            print('Face rendered', int((codes == 0).sum()))
+            print('Discarded', histogram)
 
     def close(self):
         if self._renderer is not None:

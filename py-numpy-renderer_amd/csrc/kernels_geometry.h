@@ -235,6 +235,62 @@ k_tri_count(const FrameConst fc, const uint32_t *__restrict__ valid_list, TriRec
     }
 }
 
+// Per-face result of the reference's lit pass (obj/triangular.py:101-112 with a stencil
+// buffer): a face that reached the depth stage is "rendered" when at least one of its fragments
+// has z <= the final z-buffer value (i.e. equals it) where stencil == 0, else EMPTY_Z.  Runs
+// after the visibility kernels, only when MR_FRAME_FACE_STATUS is set (obj/core.py:625-636
+// prints the histogram).  Same work split as k_tri_count; stops at the first such fragment.
+__device__ __forceinline__ bool sample_is_drawn(const FrameConst &fc, const TriRec &t, const TriClip *clips,
+                                                const double *zbuf, const int32_t *stencil, int px, int py)
+{
+    bool cov;
+    if (!sample_survives(fc, t, clips, px, py, cov)) return false;
+    float u, v, w;
+    tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
+    const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
+    const size_t at = (size_t)py * fc.width + px;
+    const bool pass = fc.system == 1 ? (zbuf[at] >= z) : (zbuf[at] <= z);
+    return pass && (int16_t)stencil[at] == 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_face_status(const FrameConst fc, const uint32_t *__restrict__ valid_list, const TriRec *__restrict__ tris,
+              const TriClip *__restrict__ clips, const double *__restrict__ zbuf, const int32_t *__restrict__ stencil,
+              uint8_t *__restrict__ status, const Counters *__restrict__ ctr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    bool valid = i < ctr->n_valid_tris;
+    const int f = valid ? (int)valid_list[i] : 0;
+    valid = valid && status[f] == FACE_OK;
+    TriRec t = {};
+    if (valid) t = tris[f];
+    const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
+    const int total = valid ? bw * bh : 0;
+    if (valid && total <= COUNT_SMALL_BOX) {
+        bool drawn = false;
+        for (int idx = 0; idx < total && !drawn; ++idx)
+            drawn = sample_is_drawn(fc, t, clips, zbuf, stencil, t.x0 + idx % bw, t.y0 + idx / bw);
+        if (!drawn) status[f] = FACE_EMPTY_Z;
+    }
+    unsigned long long big = __ballot(valid && total > COUNT_SMALL_BOX);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int fb = __shfl(f, src);
+        const TriRec tb = tris[fb];
+        const int w = tb.x1 - tb.x0;
+        const long long n = (long long)w * (tb.y1 - tb.y0);
+        bool any = false;
+        for (long long base = 0; base < n && !any; base += WAVE) {
+            const long long idx = base + lane;
+            const bool d = idx < n && sample_is_drawn(fc, tb, clips, zbuf, stencil, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w));
+            any = __ballot(d) != 0;
+        }
+        if (lane == 0 && !any) status[fb] = FACE_EMPTY_Z;
+    }
+}
+
 // plane . point >= 0 (obj/plane_intersection.py:39-40), a 1-D dot of length 4
 __device__ __forceinline__ double plane_dot(const double *P, const double *q)
 {

@@ -385,6 +385,10 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                            fs->d_quad_work.as<uint4>(), fs->quad_work_cap, fs->d_items.as<uint32_t>(), fs->item_cap,
                            fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>(), ctr);
     HIP_TRY(hipEventRecord(fs->ev[7], stream));
+    if ((fc.flags & MR_FRAME_FACE_STATUS) && fc.n_faces > 0)
+        hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
+                           fs->d_valid.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
+                           fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>(), ctr);
 
     // ---- deferred shading + finalise
     ShadeArgs sa;
@@ -748,9 +752,13 @@ int mr_read_frame_f32(mr_scene *sc, float *out)
 
 int mr_read_face_status(mr_scene *sc, uint8_t *out)
 {
-    if (!last_slot(sc)) return MR_E_INVALID;
-    (void)out;
-    return fail(MR_E_UNSUPPORTED, "per-face status of the lit pass is not implemented yet");
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    if (!(fs->last_frame.flags & MR_FRAME_FACE_STATUS))
+        return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_FACE_STATUS");
+    if (fs->last_frame.row_begin != 0 || fs->last_frame.row_end != fs->last_frame.height)
+        return fail(MR_E_INVALID, "per-face status needs the whole frame on one device (no row band)");
+    return read_back(fs->d_status, out, sc->faces.size() / 12, "face status");
 }
 
 int mr_debug_read_tile_records(mr_scene *sc, uint32_t *out, int32_t cap_tiles)

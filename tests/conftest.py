@@ -31,6 +31,8 @@ def load_golden(name):
     import numpy as np
     base = os.path.join(ROOT, "tests", "golden", name)
     data = dict(np.load(base + ".npz"))
-    with open(base + ".json") as fh:
-        meta = json.load(fh)
+    meta = {}
+    if os.path.exists(base + ".json"):
+        with open(base + ".json") as fh:
+            meta = json.load(fh)
     return data, meta

@@ -115,7 +115,9 @@ class Capture:
             st.frame = frame.copy()
             st.z = z_buffer.copy()
             if self.overlay:
-                return orig["draw_view_frustum"](frame, camera, positioned_object, z_buffer, sign)
+                orig["draw_view_frustum"](frame, camera, positioned_object, z_buffer, sign)
+                st.frame_overlay = frame.copy()
+                st.z_overlay = z_buffer.copy()
 
         core.rasterize, core.resterize_quadrangle = rasterize, resterize_quadrangle
         core.draw_view_frustum = draw_view_frustum
@@ -148,6 +150,7 @@ def render_reference(api, core, triangular, name, shadows=True, overlay=False):
                   bbox_px_quad=st.bbox_quad, n_quads=len(sil), n_quads_drawn=None,
                   n_faces=int(st.n_faces), render_seconds=round(seconds, 3))
     return types.SimpleNamespace(out=out, frame=st.frame, frame1=st.frame1, z=st.z1, z_final=st.z,
+                                 frame_overlay=getattr(st, "frame_overlay", None), z_overlay=getattr(st, "z_overlay", None),
                                  stencil=st.stencil, winner=st.winner,
                                  status=np.array(st.status, np.uint8), silhouette=np.array(sil, np.int32).reshape(-1, 3),
                                  host=host, counts=counts, stdout=log.getvalue())
@@ -165,6 +168,12 @@ def save_small(name, r):
         json.dump(dict(counts=r.counts, stdout=r.stdout), fh, indent=1)
 
 
+def save_overlay(name, r):
+    """Overlay-on variant: the uint8 frame, float frame and z-buffer AFTER obj/core.py:638."""
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), out=r.out, frame_overlay=r.frame_overlay,
+                        z_overlay=r.z_overlay)
+
+
 def save_full(name, r):
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"),
                         out=r.out, stencil=r.stencil, winner=r.winner, z_row_sums=z_row_sums(r.z),
@@ -180,12 +189,16 @@ def main():
     ap.add_argument("--full", action="store_true", help="also the 1080p BASELINE configs (minutes)")
     args = ap.parse_args()
     api, core, triangular = import_reference()
-    small = list(scenes.SMALL) + ["diablo_small_noshadow"]
+    small = list(scenes.SMALL) + ["diablo_small_noshadow"] + list(scenes.OVERLAY)
     names = args.names or (small + (list(scenes.FULL) if args.full else []))
     for name in names:
         shadows = name not in scenes.NO_SHADOW
-        r = render_reference(api, core, triangular, name, shadows=shadows)
-        (save_full if name in scenes.FULL else save_small)(name, r)
+        if name.endswith("_overlay"):
+            r = render_reference(api, core, triangular, name[:-len("_overlay")], shadows=shadows, overlay=True)
+            save_overlay(name, r)
+        else:
+            r = render_reference(api, core, triangular, name, shadows=shadows)
+            (save_full if name in scenes.FULL else save_small)(name, r)
         print(f"{name}: {r.counts}", flush=True)
 
 

@@ -237,6 +237,8 @@ FULL = {
     "c4_torus200k_1080p": (torus_floor, {"resolution": (1080, 1920), "nu": 500, "nv": 200}),
 }
 NO_SHADOW = {"c2_diablo_1080p", "diablo_small_noshadow"}
+# the same scenes with upstream's debug-frustum overlay left on (obj/core.py:638)
+OVERLAY = ["diablo_small_overlay", "diablo_floor_lh_gl_overlay", "cube_outward_overlay"]
 
 
 def build(api, name):

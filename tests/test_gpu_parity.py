@@ -149,3 +149,20 @@ def test_large_frame_properties(api):
     assert (backend.read_stencil() == 0).all()
     assert (no_shadow.astype(int) >= full.astype(int) - 1).all()      # shadows only darken
     scene.close()
+
+
+@pytest.mark.parametrize("name", SMALL + FULL)
+def test_face_status_and_stdout_match_reference(api, capsys, name):
+    """Per-face codes of the lit pass (upstream's Errors flags) and the three lines upstream
+    prints per model (obj/core.py:634-636), captured from the reference run."""
+    g, meta = load_golden(name)
+    scene = scenes.build(api, name)
+    shadows = name not in scenes.NO_SHADOW
+    backend = scene._backend()
+    backend.render(scene, shadows=shadows, face_status=True)
+    assert np.array_equal(backend.read_face_status(), g["face_status"])
+    scene.verbose = True
+    capsys.readouterr()
+    scene.render(shadows=shadows)
+    assert capsys.readouterr().out == meta["stdout"]
+    scene.close()
