@@ -47,7 +47,8 @@ enum {
     MR_FRAME_SHADOWS = 1,     /* run the shadow-volume stencil pass (obj/core.py:610-622) */
     MR_FRAME_KEEP_FLOAT = 2,  /* also keep the float32 frame (needed by mr_read_frame_f32) */
     MR_FRAME_FACE_STATUS = 4, /* also compute the per-face status histogram (obj/core.py:625-636) */
-    MR_FRAME_LIGHT_TIMING = 8 /* record only the event marks around the frame and the visibility kernels */
+    MR_FRAME_LIGHT_TIMING = 8, /* record only the event marks around the frame and the visibility kernels */
+    MR_FRAME_SKYBOX = 16      /* fill the background from the cubemap of mr_scene_set_skybox (obj/core.py:595-596) */
 };
 
 typedef struct mr_scene mr_scene;
@@ -76,6 +77,11 @@ typedef struct mr_frame_desc {
     float background[3];            /* obj/core.py:597-600 */
     uint32_t background_u8;         /* the same colour after obj/core.py:640's finalise, computed by the host:
                                        r | g << 8 | b << 16 | 1 << 24; 0 = let the device compute it */
+    /* MR_FRAME_SKYBOX only (obj/cube_map.py:83-101): the two screen-filling triangles' vertices
+     * truncated to int, [triangle][vertex][x, y], and their un-projected corner rays
+     * face @ inv(view_without_translation @ projection) / w, [triangle][vertex][x, y, z] */
+    int32_t sky_tri[12];
+    double sky_rays[18];
 } mr_frame_desc;
 
 /* One material group of a model (obj/materials.py:47-55; obj/core.py:125). */
@@ -141,6 +147,11 @@ void mr_scene_destroy(mr_scene *scene);
  * float32 (h, w, 3) image exactly as the reference stores it.  Returns the texture id (>= 0)
  * or a negative error. */
 int mr_scene_add_texture(mr_scene *scene, const float *rgb, int32_t h, int32_t w);
+
+/* Scene(skymap=CubeMap(...)) -- obj/cube_map.py:22-34: the six cubemap faces as one uint8
+ * (6, size, size, 3) stack in the reference's face order and orientation (CubeMap.textures * 255).
+ * size = 0 removes the skybox.  Used by frames that set MR_FRAME_SKYBOX. */
+int mr_scene_set_skybox(mr_scene *scene, const uint8_t *texels, int32_t size);
 
 /* Scene.add_model (obj/core.py:584-585).  Returns the model index (>= 0) or a negative error. */
 int mr_scene_add_model(mr_scene *scene, const mr_model_desc *model);

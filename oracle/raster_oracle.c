@@ -677,6 +677,57 @@ void orc_finalise(const float *frame, int32_t h, int32_t w, uint8_t *out)
     }
 }
 
+/* ------------------------------------------------------------------ skybox (cube_map.py:63-101) */
+
+/* fill_frame_from_skybox: two screen-covering triangles with integer vertices; the dots of
+ * barycentric() are therefore exact integers, converted to float32 (transformation.py:19-23). */
+static void fill_skybox(const orc_frame *fr, float *frame)
+{
+    const int W = fr->width, H = fr->height;
+    const long long S = fr->sky_size;
+    for (int t = 0; t < 2; ++t) {
+        const int32_t *tv = fr->sky_tri + t * 6;
+        const long long ax = tv[0], ay = tv[1];
+        const long long v0x = tv[2] - ax, v0y = tv[3] - ay, v1x = tv[4] - ax, v1y = tv[5] - ay;
+        const float d00 = (float)(v0x * v0x + v0y * v0y), d01 = (float)(v0x * v1x + v0y * v1y);
+        const float d11 = (float)(v1x * v1x + v1y * v1y);
+        const float den = d00 * d11 - d01 * d01;
+        if (den == 0) continue;
+        const float inv = 1.0f / den;
+        const double *r = fr->sky_rays + t * 9;
+        for (int px = 0; px < W; ++px) {
+            for (int py = 0; py < H; ++py) {
+                const long long v2x = px - ax, v2y = py - ay;
+                const float d20 = (float)(v2x * v0x + v2y * v0y), d21 = (float)(v2x * v1x + v2y * v1y);
+                const float v = (d11 * d20 - d01 * d21) * inv;
+                const float w = (d00 * d21 - d01 * d20) * inv;
+                const float u = 1.0f - v - w;
+                if (!(u >= 0 && v >= 0 && w >= 0)) continue;
+                double ray[3];
+                for (int j = 0; j < 3; ++j) ray[j] = chain3(u, v, w, r[j], r[3 + j], r[6 + j]);
+                /* CubeMap.__getitem__ (cube_map.py:63-80) */
+                int major = 0;
+                if (fabs(ray[1]) > fabs(ray[major])) major = 1;
+                if (fabs(ray[2]) > fabs(ray[major])) major = 2;
+                const double amp = ray[major];
+                const double c0 = ray[major == 0 ? 1 : 0], c1 = ray[major == 2 ? 1 : 2];
+                const double n0 = (c0 / amp + 1) / 2, n1 = (c1 / amp + 1) / 2;
+                const int side = (amp < 0 ? 1 : 0) + 2 * major;
+                long long i0 = (long long)(n0 * (double)S - 1), i1 = (long long)(n1 * (double)S - 1);
+                if (i0 < 0) i0 += S;
+                if (i1 < 0) i1 += S;
+                if (i0 < 0) i0 = 0;
+                if (i0 >= S) i0 = S - 1;
+                if (i1 < 0) i1 = 0;
+                if (i1 >= S) i1 = S - 1;
+                const uint8_t *tx = fr->sky_texels + (((size_t)side * S + i0) * S + i1) * 3;
+                float *dst = frame + ((size_t)py * W + px) * 3;
+                for (int j = 0; j < 3; ++j) dst[j] = (float)((double)tx[j] / 255.0);
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ Scene.render (core.py:587-640) */
 
 int orc_render(const orc_frame *frame, const orc_model *models, int32_t n_models,
@@ -704,6 +755,8 @@ int orc_render(const orc_frame *frame, const orc_model *models, int32_t n_models
     }
 
     frag_buf fb = { NULL, 0 };
+    if (o->frame && frame->sky_texels && frame->sky_size > 0) fill_skybox(frame, o->frame);
+
     edge_set *sets = (edge_set *)calloc((size_t)n_models, sizeof(edge_set));
     if (!sets) return -2;
     const int shadows = (frame->flags & ORC_FLAG_SHADOWS) != 0;

@@ -52,6 +52,11 @@ typedef struct orc_frame {
     double att_constant, att_linear, att_quadratic;
     double spot_edge0, spot_edge1;   /* cos(20 deg), cos(10 deg) (triangular.py:158-159) */
     float background[3];
+    /* cubemap skybox (cube_map.py:83-101); sky_texels == NULL -> plain background colour */
+    int32_t sky_size;
+    const uint8_t *sky_texels;   /* (6, size, size, 3) uint8, CubeMap.textures * 255 */
+    int32_t sky_tri[12];         /* the two triangles' screen vertices truncated to int, [t][v][xy] */
+    double sky_rays[18];         /* their un-projected corner rays / w, [t][v][xyz] */
 } orc_frame;
 
 typedef struct orc_texture {

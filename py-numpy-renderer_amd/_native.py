@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MR_OK = 0
 MR_E_OVERFLOW = -4
-FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING = 1, 2, 4, 8
+FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SKYBOX = 1, 2, 4, 8, 16
 
 
 class FrameDesc(C.Structure):
@@ -31,7 +31,8 @@ class FrameDesc(C.Structure):
                 ("light_color", C.c_double * 3), ("light_ambient", C.c_double * 3),
                 ("specular_strength", C.c_double), ("att_constant", C.c_double), ("att_linear", C.c_double),
                 ("att_quadratic", C.c_double), ("spot_edge0", C.c_double), ("spot_edge1", C.c_double),
-                ("background", C.c_float * 3), ("background_u8", C.c_uint32)]
+                ("background", C.c_float * 3), ("background_u8", C.c_uint32),
+                ("sky_tri", C.c_int32 * 12), ("sky_rays", C.c_double * 18)]
 
 
 class MaterialDesc(C.Structure):
@@ -68,6 +69,7 @@ _PROTOTYPES = {
     "mr_scene_create": (C.c_void_p, []),
     "mr_scene_destroy": (None, [C.c_void_p]),
     "mr_scene_add_texture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "mr_scene_set_skybox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_scene_add_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
     "mr_scene_clear": (C.c_int, [C.c_void_p]),
     "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
@@ -135,6 +137,12 @@ def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, fac
     # the finalised background exactly as the reference computes it (float32 ** 0.8 * 255 -> uint8)
     bg = (np.asarray(pf.background, dtype=np.float32) ** 0.8 * 255).astype(np.uint8)
     d.background_u8 = int(bg[0]) | int(bg[1]) << 8 | int(bg[2]) << 16 | 1 << 24
+    if pf.sky_tri is not None:
+        d.flags |= FRAME_SKYBOX
+        for i, v in enumerate(np.asarray(pf.sky_tri, dtype=np.int32).ravel()):
+            d.sky_tri[i] = int(v)
+        for i, v in enumerate(np.asarray(pf.sky_rays, dtype=np.float64).ravel()):
+            d.sky_rays[i] = v
     return d
 
 
@@ -148,6 +156,7 @@ class DeviceRenderer:
         if not self.handle:
             raise RuntimeError("mr_scene_create failed: " + self.lib.mr_last_error().decode())
         self._signature = None
+        self._sky_key = None
         self.last_stats = None
         self._frame = None
 
@@ -190,10 +199,23 @@ class DeviceRenderer:
             _check(self.lib.mr_scene_add_model(self.handle, C.byref(d)), "mr_scene_add_model")
         self._signature = sig
 
+    def sync_skybox(self, scene):
+        sky = scene.skybox if hasattr(scene.skybox, "texels") else None
+        key = None if sky is None else id(sky.texels)
+        if key == self._sky_key:
+            return
+        if sky is None:
+            _check(self.lib.mr_scene_set_skybox(self.handle, None, 0), "mr_scene_set_skybox")
+        else:
+            tex = np.ascontiguousarray(sky.texels, dtype=np.uint8)
+            _check(self.lib.mr_scene_set_skybox(self.handle, tex.ctypes.data, tex.shape[1]), "mr_scene_set_skybox")
+        self._sky_key = key
+
     # -- frames ---------------------------------------------------------------------------
     def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False):
         """``mr_render``: returns the uint8 band ``(rows, W, 3)`` as a NumPy array."""
         self.sync_scene(scene)
+        self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
         desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status)
         self._n_faces = sum(len(m._faces) for m in scene.models)
@@ -208,6 +230,7 @@ class DeviceRenderer:
     def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False):
         """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
         self.sync_scene(scene)
+        self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
         desc = fill_frame_desc(pf, row_band, False, light_timing)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),

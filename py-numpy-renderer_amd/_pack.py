@@ -64,6 +64,8 @@ class PackedFrame:
     spot_edge0: float
     spot_edge1: float
     background: np.ndarray
+    sky_tri: Optional[np.ndarray] = None      # (2, 3, 2) int32, cubemap skybox only
+    sky_rays: Optional[np.ndarray] = None     # (2, 3, 3) float64
 
 
 @dataclass
@@ -95,7 +97,12 @@ def pack_frame(scene, shadows=True) -> PackedFrame:
     dbg = scene.debug_camera if scene.debug_camera is not None else cam
     height, width = (int(v) for v in scene.resolution)
     sky = scene.skybox
-    if sky is not None and not hasattr(sky, "textures"):
+    sky_tri = sky_rays = None
+    if sky is not None and hasattr(sky, "textures"):
+        from .cube_map import sky_frame_constants
+        sky_tri, sky_rays = sky_frame_constants(cam)
+        background = np.zeros(3, dtype=np.float32)          # uncovered pixels stay black (frame starts at 0)
+    elif sky is not None:
         background = np.asarray(np.array(sky), dtype=np.float32).ravel()
         if background.size != 3:
             raise ValueError("skymap colour must have 3 components")
@@ -117,7 +124,7 @@ def pack_frame(scene, shadows=True) -> PackedFrame:
         att_constant=float(light.constant), att_linear=float(light.linear),
         att_quadratic=float(light.quadratic),
         spot_edge0=float(np.cos(np.deg2rad(20))), spot_edge1=float(np.cos(np.deg2rad(10))),
-        background=background)
+        background=background, sky_tri=sky_tri, sky_rays=sky_rays)
 
 
 def _texture_id(tex, textures, seen):

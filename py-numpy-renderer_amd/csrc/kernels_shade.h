@@ -24,6 +24,7 @@ struct ShadeArgs {
     const Texture *textures;
     const int32_t *winner;
     const int32_t *stencil;    // 32-bit accumulator; the reference's buffer is its low 16 bits
+    const uint8_t *sky;        // cubemap texels (6, S, S, 3) or null
     float *frame;          // optional float frame (row = screen y), may be null
     uint8_t *out;          // band of the final frame, row 0 = top row of the band
 };
@@ -130,6 +131,53 @@ __device__ __forceinline__ double np_power(double x, double e)
     return pow(x, e);
 }
 
+// Skybox colour of one background pixel (obj/cube_map.py:63-101).  Two screen-covering
+// triangles with INTEGER vertices: the barycentric dots are exact integers rounded to float32,
+// the later triangle overwrites the earlier on their shared diagonal, and the pixels neither
+// covers (a few along the edges, because the vertices were truncated) stay black.
+__device__ __forceinline__ void sky_color(const FrameConst &fc, const uint8_t *sky, int px, int py, float rgb[3])
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    const long long S = fc.sky_size;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int32_t *tv = fc.sky_tri + t * 6;
+        const long long ax = tv[0], ay = tv[1];
+        const long long v0x = tv[2] - ax, v0y = tv[3] - ay, v1x = tv[4] - ax, v1y = tv[5] - ay;
+        const long long v2x = px - ax, v2y = py - ay;
+        const float d00 = (float)(v0x * v0x + v0y * v0y), d01 = (float)(v0x * v1x + v0y * v1y);
+        const float d11 = (float)(v1x * v1x + v1y * v1y);
+        const float d20 = (float)(v2x * v0x + v2y * v0y), d21 = (float)(v2x * v1x + v2y * v1y);
+        const float den = d00 * d11 - d01 * d01;
+        if (den == 0) continue;
+        const float inv = 1.0f / den;
+        const float v = (d11 * d20 - d01 * d21) * inv;
+        const float w = (d00 * d21 - d01 * d20) * inv;
+        const float u = 1.0f - v - w;
+        if (!(u >= 0 && v >= 0 && w >= 0)) continue;
+        const double *r = fc.sky_rays + t * 9;
+        double ray[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ray[j] = chain3((double)u, (double)v, (double)w, r[j], r[3 + j], r[6 + j]);
+        // CubeMap.__getitem__: major axis (first maximum of |.|), the other two components / it
+        int major = 0;
+        if (fabs(ray[1]) > fabs(ray[major])) major = 1;
+        if (fabs(ray[2]) > fabs(ray[major])) major = 2;
+        const double amp = ray[major];
+        const double c0 = ray[major == 0 ? 1 : 0], c1 = ray[major == 2 ? 1 : 2];
+        const double n0 = (c0 / amp + 1) / 2, n1 = (c1 / amp + 1) / 2;
+        const int side = (amp < 0 ? 1 : 0) + 2 * major;
+        long long i0 = (long long)(n0 * (double)S - 1), i1 = (long long)(n1 * (double)S - 1);
+        if (i0 < 0) i0 += S;
+        if (i1 < 0) i1 += S;
+        i0 = i0 < 0 ? 0 : (i0 >= S ? S - 1 : i0);
+        i1 = i1 < 0 ? 0 : (i1 >= S ? S - 1 : i1);
+        const uint8_t *tx = sky + (((size_t)side * S + i0) * S + i1) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rgb[j] = (float)((double)tx[j] / 255.0);
+    }
+}
+
 __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v); }
 
 __global__ void __launch_bounds__(256)
@@ -145,7 +193,9 @@ k_shade(const FrameConst fc, const ShadeArgs a)
 
     float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
     const int f = a.winner[at];
-    if (f < 0 && (fc.background_u8 >> 24)) {
+    if (f < 0 && (fc.flags & MR_FRAME_SKYBOX) && a.sky) {
+        sky_color(fc, a.sky, px, py, rgb);
+    } else if (f < 0 && (fc.background_u8 >> 24)) {
         // background: the host already finalised the colour with NumPy itself (obj/core.py:600,640)
         if (a.frame) { a.frame[at * 3 + 0] = rgb[0]; a.frame[at * 3 + 1] = rgb[1]; a.frame[at * 3 + 2] = rgb[2]; }
         uint8_t *o = a.out + ((size_t)(fc.band_y1 - 1 - py) * W + px) * 3;

@@ -135,6 +135,8 @@ struct mr_scene {
 
     // ---- device copies of the static scene
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
+    DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
+    int32_t sky_size = 0;
 
     // ---- frame slots, one per stream that has rendered this scene
     std::vector<std::unique_ptr<FrameSlot>> slots;
@@ -264,6 +266,9 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
         fc.background[j] = fr->background[j];
     }
     fc.background_u8 = (uint32_t)fr->background_u8;
+    std::memcpy(fc.sky_tri, fr->sky_tri, sizeof fc.sky_tri);
+    std::memcpy(fc.sky_rays, fr->sky_rays, sizeof fc.sky_rays);
+    fc.sky_size = sc->sky_size;
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
     fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;
@@ -397,6 +402,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
     sa.materials = sc->d_materials.as<Material>(); sa.textures = sc->d_textures.as<Texture>();
     sa.winner = fs->d_winner.as<int32_t>(); sa.stencil = fs->d_stencil.as<int32_t>();
+    sa.sky = sc->sky_size > 0 ? sc->d_sky.as<uint8_t>() : nullptr;
     sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
     sa.out = d_out;
     const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
@@ -541,7 +547,7 @@ void mr_scene_destroy(mr_scene *sc)
     if (!sc) return;
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
-                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc };
+                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_sky };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();
     delete sc;
@@ -562,6 +568,22 @@ int mr_scene_add_texture(mr_scene *sc, const float *rgb, int32_t h, int32_t w)
     sc->textures.push_back({ static_cast<const float *>(d), h, w });
     sc->dirty = true;
     return (int)sc->textures.size() - 1;
+}
+
+int mr_scene_set_skybox(mr_scene *sc, const uint8_t *texels, int32_t size)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    if (size < 0 || size > 16384 || (size > 0 && !texels)) return fail(MR_E_INVALID, "bad cubemap");
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    sc->sky_size = 0;
+    if (size == 0) return MR_OK;
+    const size_t bytes = (size_t)6 * size * size * 3;
+    HIP_TRY(sc->d_sky.ensure(bytes));
+    HIP_TRY(hipMemcpy(sc->d_sky.p, texels, bytes, hipMemcpyHostToDevice));
+    sc->sky_size = size;
+    return MR_OK;
 }
 
 int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)

@@ -56,6 +56,9 @@ struct FrameConst {
     double spot_edge0, spot_edge1;
     float background[3];
     uint32_t background_u8;      // finalised background r | g << 8 | b << 16 | 1 << 24 (0 = not given)
+    int32_t sky_tri[12];         // skybox triangles' integer screen vertices [t][v][xy]
+    int32_t sky_size, sky_pad;   // cubemap face size
+    double sky_rays[18];         // their un-projected corner rays [t][v][xyz]
 };
 
 // Output of the vertex kernel: everything obj/triangular.py:36-45 derives per face corner,

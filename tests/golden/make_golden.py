@@ -47,8 +47,9 @@ def import_reference():
     import triangular
     import transformation
     from obj.lightning import Lightning      # the module object triangular.py compares against (as obj/main.py:9)
+    from obj.cube_map import CubeMap         # the class core.py's isinstance() test refers to (obj/core.py:8)
     api = types.SimpleNamespace(
-        Model=core.Model, Camera=core.Camera, Light=core.Light, Scene=core.Scene, Lightning=Lightning,
+        Model=core.Model, Camera=core.Camera, Light=core.Light, Scene=core.Scene, Lightning=Lightning, CubeMap=CubeMap,
         SYSTEM=transformation.SYSTEM, SUBSYSTEM=transformation.SUBSYSTEM, scale=transformation.scale,
         translation=transformation.translation, rotate_xyz=transformation.rotate_xyz)
     return api, core, triangular
@@ -198,7 +199,7 @@ def main():
             save_overlay(name, r)
         else:
             r = render_reference(api, core, triangular, name, shadows=shadows)
-            (save_full if name in scenes.FULL else save_small)(name, r)
+            (save_full if name in scenes.FULL or name in scenes.HUGE else save_small)(name, r)
         print(f"{name}: {r.counts}", flush=True)
 
 

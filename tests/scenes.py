@@ -26,7 +26,7 @@ def product_api():
     import py_numpy_renderer_amd as pkg
     from py_numpy_renderer_amd import transformation as tr
     return SimpleNamespace(Model=pkg.Model, Camera=pkg.Camera, Light=pkg.Light, Scene=pkg.Scene,
-                           Lightning=pkg.Lightning, SYSTEM=pkg.SYSTEM, SUBSYSTEM=pkg.SUBSYSTEM,
+                           Lightning=pkg.Lightning, SYSTEM=pkg.SYSTEM, SUBSYSTEM=pkg.SUBSYSTEM, CubeMap=pkg.CubeMap,
                            scale=tr.scale, translation=tr.translation, rotate_xyz=tr.rotate_xyz)
 
 
@@ -200,6 +200,27 @@ def torus_floor(api, resolution=(1080, 1920), nu=500, nv=200):
     return _scene(api, cam, dbg, _std_light(api), resolution, [_torus(api, nu, nv), _floor(api)])
 
 
+def _cubemap(api):
+    d = os.path.join(ASSETS, "cubemap")            # face assignment of obj/main.py:101-106
+    return api.CubeMap(back=os.path.join(d, "neg-z.jpg"), front=os.path.join(d, "pos-z.jpg"),
+                       top=os.path.join(d, "pos-y.jpg"), bottom=os.path.join(d, "neg-y.jpg"),
+                       left=os.path.join(d, "neg-x.jpg"), right=os.path.join(d, "pos-x.jpg"))
+
+
+def cube_skybox(api, resolution=(135, 240)):
+    """G5: the outward cube + floor in front of the 512^2 cubemap skybox."""
+    sc = cube_outward(api, resolution=resolution)
+    sc.skybox = _cubemap(api)
+    return sc
+
+
+def torus_skybox(api, resolution=(2160, 3840), nu=1000, nv=500):
+    """c5: 1M-triangle torus + floor + cubemap skybox at 3840x2160 (and reduced variants)."""
+    sc = torus_floor(api, resolution=resolution, nu=nu, nv=nv)
+    sc.skybox = _cubemap(api)
+    return sc
+
+
 def tetra_bare(api, resolution=(120, 160)):
     """Model without vertex normals and without textures on a textured floor: Kd colour,
     face-normal shading, GL/RH projection."""
@@ -228,6 +249,8 @@ SMALL = {
     "torus_spot": (torus_spot, {}),
     "tetra_bare": (tetra_bare, {}),
     "diablo_closeup": (diablo_closeup, {}),
+    "cube_skybox": (cube_skybox, {}),
+    "torus_skybox_small": (torus_skybox, {"resolution": (216, 384), "nu": 60, "nv": 30}),
 }
 
 # BASELINE.json configs at full size: only the uint8 frame, winner map, stencil and z row sums are kept
@@ -235,6 +258,10 @@ FULL = {
     "c2_diablo_1080p": (diablo_small, {"resolution": (1080, 1920)}),       # rendered with shadows off
     "c3_diablo_floor_1080p": (diablo_floor, {"resolution": (1080, 1920)}),
     "c4_torus200k_1080p": (torus_floor, {"resolution": (1080, 1920), "nu": 500, "nv": 200}),
+}
+# BASELINE.json configs[4]; its capture takes the reference ~8 minutes and is generated separately
+HUGE = {
+    "c5_torus1m_4k_skybox": (torus_skybox, {"resolution": (2160, 3840), "nu": 1000, "nv": 500}),
 }
 NO_SHADOW = {"c2_diablo_1080p", "diablo_small_noshadow"}
 # the same scenes with upstream's debug-frustum overlay left on (obj/core.py:638)
@@ -244,5 +271,5 @@ OVERLAY = ["diablo_small_overlay", "diablo_floor_lh_gl_overlay", "cube_outward_o
 def build(api, name):
     if name == "diablo_small_noshadow":
         return diablo_small(api)
-    fn, kw = {**SMALL, **FULL}[name]
+    fn, kw = {**SMALL, **FULL, **HUGE}[name]
     return fn(api, **kw)
