@@ -14,22 +14,23 @@ namespace mr {
 
 __global__ void __launch_bounds__(256)
 k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
-         Counters *__restrict__ ctr)
+         VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *ctr = Counters{};      // first kernel of the frame: every later one is stream-ordered after it
     if (i >= fc.n_vertices) return;
     double v[4] = { verts[i * 4 + 0], verts[i * 4 + 1], verts[i * 4 + 2], verts[i * 4 + 3] };
     VertexOut o;
+    VertexClip oc;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        o.clip[j] = row_times_col(v, fc.mvp, j);
-        o.clipd[j] = row_times_col(v, fc.debug_mvp, j);
+        oc.clip[j] = row_times_col(v, fc.mvp, j);
+        oc.clipd[j] = row_times_col(v, fc.debug_mvp, j);
     }
-    double depth = 1.0 / o.clip[3];
+    double depth = 1.0 / oc.clip[3];
     double ndc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ndc[j] = o.clip[j] * depth;
+    for (int j = 0; j < 4; ++j) ndc[j] = oc.clip[j] * depth;
     o.sx = row_times_col(ndc, fc.viewport, 0);
     o.sy = row_times_col(ndc, fc.viewport, 1);
     o.sz = row_times_col(ndc, fc.viewport, 2);
@@ -41,11 +42,12 @@ k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__res
     // when all three corners carry this flag the strict test of obj/triangular.py:85-87 cannot
     // fail for any fragment of the face and need not be evaluated.
     const double k = 1.0 - 1e-12;
-    const double wl = o.clip[3] * k, wd = o.clipd[3] * k;
-    o.safe = (fabs(o.clip[0]) < wl && fabs(o.clip[1]) < wl && fabs(o.clip[2]) < wl &&
-              fabs(o.clipd[0]) < wd && fabs(o.clipd[1]) < wd && fabs(o.clipd[2]) < wd) ? 1 : 0;
+    const double wl = oc.clip[3] * k, wd = oc.clipd[3] * k;
+    o.safe = (fabs(oc.clip[0]) < wl && fabs(oc.clip[1]) < wl && fabs(oc.clip[2]) < wl &&
+              fabs(oc.clipd[0]) < wd && fabs(oc.clipd[1]) < wd && fabs(oc.clipd[2]) < wd) ? 1 : 0;
     o.pad = 0;
     out[i] = o;
+    out_clip[i] = oc;
 }
 
 // unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130),
@@ -78,11 +80,48 @@ __device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *
     return chain3(n[0], n[1], n[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0;
 }
 
+// Survivors of coverage + clip among the first `limit` samples of a triangle's pixel box, as
+// seen by one lane walking the box sample by sample (stops at two).
+struct CountResult { int found; unsigned int covered; };
+
+__device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const TriClip *clips,
+                                                int px, int py, bool &covered_in_band)
+{
+    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    float u, v, w;
+    tri_bary(t, (double)px, (double)py, single, u, v, w);
+    bool ok = u >= 0 && v >= 0 && w >= 0;
+    covered_in_band = ok && py >= fc.band_y0 && py < fc.band_y1;
+    if (ok && (t.flags & TF_CLIP)) {
+        const TriClip &c = clips[t.face];
+        double p[3];
+        persp_bary(c.dp, u, v, w, single, p);
+        ok = inside_clip(p, c.clip) && inside_clip(p, c.clipd);
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, Counters *ctr, int f, uint32_t flags,
+                                             int found, unsigned int covered)
+{
+    if (found == 0) {
+        // the face never reaches the visibility kernel: account for its fragments here
+        // (the fragment count is taken before the clip, obj/triangular.py:78)
+        status[f] = FACE_CLIPPED;
+        if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
+    } else if (found == 1) {
+        tris[f].flags = flags | TF_SINGLE_Z;
+    }
+}
+
+constexpr int COUNT_SMALL_BOX = 32;   // pixel boxes up to this size are walked by a single lane
+
 __global__ void __launch_bounds__(256)
 k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
             const double *__restrict__ verts, const VertexOut *__restrict__ vout,
-            TriRec *__restrict__ tris, TriClip *__restrict__ clips, uint8_t *__restrict__ status,
-            uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list, Counters *__restrict__ ctr)
+            const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris, TriClip *__restrict__ clips,
+            uint8_t *__restrict__ status, uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list,
+            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr)
 {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= fc.n_faces) return;
@@ -132,70 +171,62 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     t.face = f;
     status[f] = FACE_OK;
     if (box <= 0) { status[f] = FACE_CLIPPED; return; }    // no sample inside the box
+
+    // How many fragments survive coverage + clip (0 -> CLIPPED, 1 -> z is a dot, TF_SINGLE_Z)?
+    // A small pixel box that needs no clip test is settled right here, by this lane, over the
+    // WHOLE frame (not just this device's band); the rest is left to k_tri_count.
+    const bool count_here = !need_clip && box <= COUNT_SMALL_BOX;
+    if (count_here) {
+        const int bw = bx1 - bx0;
+        int found = 0;
+        unsigned int covered = 0;
+        for (int idx = 0; idx < (int)box && found < 2; ++idx) {
+            bool cov;
+            found += sample_survives(fc, t, nullptr, bx0 + idx % bw, by0 + idx / bw, cov) ? 1 : 0;
+            covered += cov ? 1u : 0u;
+        }
+        if (found == 0) {
+            status[f] = FACE_CLIPPED;              // never reaches the visibility kernel: count its fragments here
+            if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
+            return;
+        }
+        if (found == 1) t.flags |= TF_SINGLE_Z;
+    }
     tris[f] = t;
     TriClip &cl = clips[f];
     cl.dp[0] = A.depth; cl.dp[1] = B.depth; cl.dp[2] = C.depth;
     if (need_clip) {
+        const VertexClip ca = vclip[va], cb = vclip[vb], cc = vclip[vc];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            cl.clip[0][j] = A.clip[j]; cl.clip[1][j] = B.clip[j]; cl.clip[2][j] = C.clip[j];
-            cl.clipd[0][j] = A.clipd[j]; cl.clipd[1][j] = B.clipd[j]; cl.clipd[2][j] = C.clipd[j];
+            cl.clip[0][j] = ca.clip[j]; cl.clip[1][j] = cb.clip[j]; cl.clip[2][j] = cc.clip[j];
+            cl.clipd[0][j] = ca.clipd[j]; cl.clipd[1][j] = cb.clipd[j]; cl.clipd[2][j] = cc.clipd[j];
         }
     }
     uint32_t slot = atomicAdd(&ctr->n_valid_tris, 1u);
     valid_list[slot] = (uint32_t)f;
-}
-
-// Survivors of coverage + clip among the first `limit` samples of a triangle's pixel box, as
-// seen by one lane walking the box sample by sample (stops at two).
-struct CountResult { int found; unsigned int covered; };
-
-__device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const TriClip *clips,
-                                                int px, int py, bool &covered_in_band)
-{
-    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
-    float u, v, w;
-    tri_bary(t, (double)px, (double)py, single, u, v, w);
-    bool ok = u >= 0 && v >= 0 && w >= 0;
-    covered_in_band = ok && py >= fc.band_y0 && py < fc.band_y1;
-    if (ok && (t.flags & TF_CLIP)) {
-        const TriClip &c = clips[t.face];
-        double p[3];
-        persp_bary(c.dp, u, v, w, single, p);
-        ok = inside_clip(p, c.clip) && inside_clip(p, c.clipd);
-    }
-    return ok;
-}
-
-__device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, Counters *ctr, int f, uint32_t flags,
-                                             int found, unsigned int covered)
-{
-    if (found == 0) {
-        // the face never reaches the visibility kernel: account for its fragments here
-        // (the fragment count is taken before the clip, obj/triangular.py:78)
-        status[f] = FACE_CLIPPED;
-        if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
-    } else if (found == 1) {
-        tris[f].flags = flags | TF_SINGLE_Z;
+    if (!count_here) {
+        slot = atomicAdd(&ctr->n_count, 1u);
+        count_list[slot] = (uint32_t)f;
     }
 }
-
-constexpr int COUNT_SMALL_BOX = 32;   // pixel boxes up to this size are walked by a single lane
 
 // Counts, per set-up triangle, the fragments that survive coverage + clip over the WHOLE frame
 // (not just this device's band), stopping as soon as two are found:
 //   0 -> the reference returns CLIPPED for the face; 1 -> z = bar @ zlin is a dot (TF_SINGLE_Z).
-// One lane per triangle: small pixel boxes (nearly all of a dense mesh) are walked by their
-// lane; the others are taken one at a time by the whole wavefront, 64 samples per step,
-// starting at the chunk that holds the centroid.
-__global__ void __launch_bounds__(256)
-k_tri_count(const FrameConst fc, const uint32_t *__restrict__ valid_list, TriRec *__restrict__ tris,
-            const TriClip *__restrict__ clips, uint8_t *__restrict__ status, Counters *__restrict__ ctr)
+// Only the faces k_tri_setup could not settle itself arrive here (pixel boxes over 32 samples,
+// or a per-fragment clip test): small boxes are walked by one lane, the others are taken one at
+// a time by the whole wavefront, 64 samples per step, starting at the chunk with the centroid.
+__device__ __forceinline__ void
+tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
+               const TriClip *__restrict__ clips, uint8_t *__restrict__ status, Counters *__restrict__ ctr,
+               uint32_t block, uint32_t n_blocks)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
-    const bool valid = i < ctr->n_valid_tris;
-    const int f = valid ? (int)valid_list[i] : 0;
+    const uint32_t n_count = ctr->n_count;
+  for (uint32_t i = block * blockDim.x + threadIdx.x; i - lane < n_count; i += n_blocks * blockDim.x) {
+    const bool valid = i < n_count;
+    const int f = valid ? (int)count_list[i] : 0;
     TriRec t = {};
     if (valid) t = tris[f];
     const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
@@ -233,6 +264,7 @@ k_tri_count(const FrameConst fc, const uint32_t *__restrict__ valid_list, TriRec
         }
         if (lane == 0) count_finish(tris, status, ctr, fb, tb.flags, found, covered);
     }
+  }
 }
 
 // Per-face result of the reference's lit pass (obj/triangular.py:101-112 with a stencil
@@ -344,12 +376,12 @@ __device__ int clip_polygon(const double *planes, double (*poly)[4], int n)
 // One thread per unique undirected edge of the scene.  An edge is on the silhouette when an
 // odd number of its incident light-facing faces toggled it; it keeps the orientation of the
 // last such face in face order (set add/discard semantics of obj/triangular.py:294-302).
-__global__ void __launch_bounds__(256)
-k_silhouette(const FrameConst fc, const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
-             const int32_t *__restrict__ faces, const uint8_t *__restrict__ lit,
-             int32_t *__restrict__ sil_edges, uint32_t quad_cap, Counters *__restrict__ ctr)
+__device__ __forceinline__ void
+silhouette_body(const FrameConst &fc, const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
+                const int32_t *__restrict__ faces, const uint8_t *__restrict__ lit,
+                int32_t *__restrict__ sil_edges, uint32_t quad_cap, Counters *__restrict__ ctr, uint32_t block)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int e = (int)(block * blockDim.x + threadIdx.x);
     if (e >= fc.n_edges) return;
     uint32_t cnt = 0, last = 0;
     for (uint32_t k = edge_offset[e]; k < edge_offset[e + 1]; ++k) {
@@ -366,6 +398,25 @@ k_silhouette(const FrameConst fc, const uint32_t *__restrict__ edge_offset, cons
         sil_edges[sslot * 3 + 1] = ia;
         sil_edges[sslot * 3 + 2] = ib;
     }
+}
+
+// Two independent stages that both follow k_tri_setup share one launch (a launch of a nearly
+// empty kernel costs ~10 us of latency on its own): workgroups [0, count_blocks) settle the
+// survivor counts k_tri_setup left open, the remaining sil_blocks detect silhouette edges.
+__global__ void __launch_bounds__(256)
+k_silhouette_and_count(const FrameConst fc, const uint32_t *__restrict__ edge_offset,
+                       const uint32_t *__restrict__ edge_inc, const int32_t *__restrict__ faces,
+                       const uint8_t *__restrict__ lit, int32_t *__restrict__ sil_edges, uint32_t quad_cap,
+                       const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
+                       const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
+                       Counters *__restrict__ ctr, uint32_t sil_blocks, uint32_t count_blocks)
+{
+    // the few counting workgroups come first so that their (latency-bound) work is in flight
+    // while the silhouette workgroups are still being dispatched
+    if (blockIdx.x < count_blocks)
+        tri_count_body(fc, count_list, tris, clips, status, ctr, blockIdx.x, count_blocks);
+    else
+        silhouette_body(fc, edge_offset, edge_inc, faces, lit, sil_edges, quad_cap, ctr, blockIdx.x - count_blocks);
 }
 
 // Shadow-quad set-up: extrusion away from the light, Sutherland-Hodgman clipping against the

@@ -161,11 +161,10 @@ __device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArg
 }
 
 template <bool FILL>
-__global__ void __launch_bounds__(256)
-k_bin_classify(const FrameConst fc, const BinArgs a)
+__device__ __forceinline__ void bin_classify_body(const FrameConst &fc, const BinArgs &a, uint32_t block)
 {
     const uint32_t n_tris = a.ctr->n_valid_tris, n_quads = min(a.ctr->n_quads_drawn, a.quad_cap);
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t u = block * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
     bool is_quad = false;
     uint32_t id = 0;
@@ -228,14 +227,13 @@ k_bin_classify(const FrameConst fc, const BinArgs a)
 }
 
 template <bool FILL>
-__global__ void __launch_bounds__(256)
-k_bin_large(const FrameConst fc, const BinArgs a)
+__device__ __forceinline__ void bin_large_body(const FrameConst &fc, const BinArgs &a, uint32_t block, uint32_t n_blocks)
 {
     const uint32_t n_tris = a.ctr->n_valid_tris, n_quads = min(a.ctr->n_quads_drawn, a.quad_cap);
     const uint32_t n_work = min(a.ctr->n_work, a.work_cap);
     const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t waves = gridDim.x * (blockDim.x / WAVE);
-    for (uint32_t w = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE; w < n_work; w += waves) {
+    const uint32_t waves = n_blocks * (blockDim.x / WAVE);
+    for (uint32_t w = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; w < n_work; w += waves) {
         const uint2 item = a.work[w];
         bool is_quad;
         uint32_t id;
@@ -249,6 +247,24 @@ k_bin_large(const FrameConst fc, const BinArgs a)
         if (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0))
             bin_emit<FILL>(fc, a, pair_class(fc, is_quad, pb, tx, ty), id, tx, ty);
     }
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_bin_classify(const FrameConst fc, const BinArgs a) { bin_classify_body<FILL>(fc, a, blockIdx.x); }
+
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_bin_large(const FrameConst fc, const BinArgs a) { bin_large_body<FILL>(fc, a, blockIdx.x, gridDim.x); }
+
+// Fill pass in one launch: after the scan the small-primitive fill (+ quad work items) and the
+// large-primitive fill are independent, so workgroups [0, large_blocks) do the second and the
+// remaining classify_blocks the first.
+__global__ void __launch_bounds__(256)
+k_bin_fill(const FrameConst fc, const BinArgs a, uint32_t classify_blocks, uint32_t large_blocks)
+{
+    if (blockIdx.x < large_blocks) bin_large_body<true>(fc, a, blockIdx.x, large_blocks);
+    else bin_classify_body<true>(fc, a, blockIdx.x - large_blocks);
 }
 
 // Exclusive scan of the BIN_CLASSES * n_tiles bin counts by one workgroup of 1024 threads,

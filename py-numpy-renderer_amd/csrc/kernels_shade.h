@@ -183,12 +183,13 @@ __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v
 __global__ void __launch_bounds__(256)
 k_shade(const FrameConst fc, const ShadeArgs a)
 {
+    // one workgroup per 16x16 pixel tile (the visibility kernel's tiles): neighbouring pixels
+    // share winners, so the gathers of records, attributes and texels stay in a few cache lines
     const int W = fc.width;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)W * (fc.band_y1 - fc.band_y0);
-    if (idx >= total) return;
-    const int px = (int)(idx % W);
-    const int py = fc.band_y0 + (int)(idx / W);
+    const int tile = (int)blockIdx.x;
+    const int px = (tile % fc.tiles_x) * TILE_W + ((int)threadIdx.x & (TILE_W - 1));
+    const int py = (tile / fc.tiles_x + fc.tile_y0) * TILE_H + (int)threadIdx.x / TILE_W;
+    if (px >= W || py < fc.band_y0 || py >= fc.band_y1) return;
     const size_t at = (size_t)py * W + px;
 
     float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };

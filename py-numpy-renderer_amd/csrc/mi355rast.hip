@@ -85,7 +85,7 @@ constexpr int EVENT_RING = 64, N_MARKS = 10;
 // Everything one in-flight frame writes.
 struct FrameSlot {
     hipStream_t stream = nullptr;                 // the stream this slot serves
-    DevBuf d_vout, d_tris, d_clips, d_status, d_lit, d_valid, d_quads, d_sil, d_counters;
+    DevBuf d_vout, d_vclip, d_tris, d_clips, d_status, d_lit, d_valid, d_count_list, d_quads, d_sil, d_counters;
     DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_quad_work, d_tile_stats;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
     uint32_t item_cap = 0, work_cap = 0, quad_cap = 0, quad_work_cap = 0;
@@ -104,7 +104,7 @@ struct FrameSlot {
     void reset_caps() { item_cap = work_cap = quad_cap = quad_work_cap = 0; bins_zeroed_for = 0; have_frame = false; }
     void release()
     {
-        DevBuf *bufs[] = { &d_vout, &d_tris, &d_clips, &d_status, &d_lit, &d_valid, &d_quads, &d_sil, &d_counters,
+        DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_clips, &d_status, &d_lit, &d_valid, &d_quads, &d_sil, &d_counters,
                            &d_bin_count, &d_bin_offset, &d_items, &d_work, &d_quad_work, &d_tile_stats,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
@@ -296,6 +296,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     if (fs->quad_work_cap == 0) fs->quad_work_cap = (uint32_t)n_tiles + (1u << 16);
 
     HIP_TRY(fs->d_vout.ensure(nV * sizeof(VertexOut)));
+    HIP_TRY(fs->d_vclip.ensure(nV * sizeof(VertexClip)));
+    HIP_TRY(fs->d_count_list.ensure(nF * sizeof(uint32_t)));
     HIP_TRY(fs->d_tris.ensure(nF * sizeof(TriRec)));
     HIP_TRY(fs->d_clips.ensure(nF * sizeof(TriClip)));
     HIP_TRY(fs->d_status.ensure(nF));
@@ -334,22 +336,27 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
 
     // ---- geometry
     hipLaunchKernelGGL(k_vertex, dim3(blocks_for(fc.n_vertices, 256)), dim3(256), 0, stream, fc,
-                       sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), ctr);
+                       sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr);
     if (fc.n_faces > 0)
         hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
-                           fs->d_vout.as<VertexOut>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                           fs->d_status.as<uint8_t>(), fs->d_lit.as<uint8_t>(), fs->d_valid.as<uint32_t>(), ctr);
+                           fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), fs->d_tris.as<TriRec>(),
+                           fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), fs->d_lit.as<uint8_t>(),
+                           fs->d_valid.as<uint32_t>(), fs->d_count_list.as<uint32_t>(), ctr);
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
-    if (fc.n_faces > 0)
-        hipLaunchKernelGGL(k_tri_count, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream,
-                           fc, fs->d_valid.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                           fs->d_status.as<uint8_t>(), ctr);
+    {
+        // silhouette detection and the leftover survivor counts are independent: one launch
+        const unsigned sil_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, 256) : 0u;
+        const unsigned count_blocks = fc.n_faces > 0 ? std::min(64u, blocks_for(fc.n_faces, 256)) : 0u;
+        if (sil_blocks + count_blocks > 0)
+            hipLaunchKernelGGL(k_silhouette_and_count, dim3(sil_blocks + count_blocks), dim3(256), 0, stream, fc,
+                               sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
+                               fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap,
+                               fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
+                               fs->d_status.as<uint8_t>(), ctr, sil_blocks, count_blocks);
+    }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
     if (shadows && fc.n_edges > 0) {
-        hipLaunchKernelGGL(k_silhouette, dim3(blocks_for(fc.n_edges, 256)), dim3(256), 0, stream, fc,
-                           sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
-                           fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap, ctr);
         const long long max_sil = std::min<long long>(fc.n_edges, fs->quad_cap);
         hipLaunchKernelGGL(k_quad_setup, dim3((unsigned)std::min<long long>(1024, blocks_for(max_sil * QS_LANES, 64))),
                            dim3(64), 0, stream, fc, fs->d_sil.as<int32_t>(), sc->d_verts.as<double>(),
@@ -368,14 +375,14 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ba.quad_work = fs->d_quad_work.as<uint4>(); ba.quad_work_cap = fs->quad_work_cap;
     const long long n_prims_max = (long long)fc.n_faces + (shadows ? std::min<long long>(fc.n_edges, fs->quad_cap) : 0);
     const unsigned classify_blocks = blocks_for(std::max<long long>(n_prims_max, n_tiles), 256);
-    const unsigned large_blocks = 1024;      // grid-stride over the work items, 4 wavefronts per block
+    const unsigned large_blocks = 512;       // grid-stride over the work items, 4 wavefronts per block
     hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
     hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[4], stream));
     hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, fs->d_bin_count.as<uint32_t>(),
                        fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr);
-    hipLaunchKernelGGL((k_bin_classify<true>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
-    hipLaunchKernelGGL((k_bin_large<true>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
+    hipLaunchKernelGGL(k_bin_fill, dim3(classify_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
+                       classify_blocks, large_blocks);
     HIP_TRY(hipEventRecord(fs->ev[5], stream));
 
     // ---- visibility: coverage, z, winner; then the shadow volumes' stencil counts
@@ -405,8 +412,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.sky = sc->sky_size > 0 ? sc->d_sky.as<uint8_t>() : nullptr;
     sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
     sa.out = d_out;
-    const long long band_px = (long long)fc.width * (fc.band_y1 - fc.band_y0);
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(band_px, 256)), dim3(256), 0, stream, fc, sa);
+    hipLaunchKernelGGL(k_shade, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc, sa);
     HIP_TRY(hipEventRecord(fs->ev[8], stream));
     HIP_TRY(hipGetLastError());
     fs->last_frame = *fr;

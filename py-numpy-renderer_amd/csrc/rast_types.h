@@ -62,14 +62,18 @@ struct FrameConst {
 };
 
 // Output of the vertex kernel: everything obj/triangular.py:36-45 derives per face corner,
-// computed once per unique vertex.
-struct VertexOut {
+// computed once per unique vertex.  The clip-space coordinates go to a side array: a face whose
+// three vertices are flagged `safe` never reads them.
+struct alignas(16) VertexOut {
     double sx, sy, sz, depth;    // screen x, y, z and 1/clip.w
-    double clip[4];              // v @ camera.MVP
-    double clipd[4];             // v @ debug_camera.MVP
     double zlin;                 // linearize_z(sz)
     int32_t safe;                // strictly inside both clip volumes with margin (see k_vertex)
     int32_t pad;
+};
+static_assert(sizeof(VertexOut) == 48, "VertexOut layout");
+struct alignas(16) VertexClip {
+    double clip[4];              // v @ camera.MVP
+    double clipd[4];             // v @ debug_camera.MVP
 };
 
 // Triangle set-up record walked by the visibility kernel: the per-face constants of
@@ -125,6 +129,8 @@ struct Texture {
 struct Counters {
     unsigned long long frag_tri, frag_quad, covered_px, lit_px, stencil_updates;
     unsigned int n_valid_tris, n_quads, n_quads_drawn;
+    unsigned int n_count;        // faces whose survivor count is left to k_tri_count
+    unsigned int pad2;
     unsigned int tri_bin_total, quad_bin_total;
     unsigned int n_work;         // (large primitive, 64-tile chunk) work items of the binning pass
     unsigned int n_quad_work;    // (tile, quad batch) work items of the stencil pass

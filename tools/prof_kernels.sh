@@ -4,7 +4,7 @@ tag=${1:-x}; steps=${2:-100}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps $steps --warmup 10 --no-cpu-baseline > $out/bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps $steps --warmup 10 --no-cpu-baseline --frames-in-flight 1 > $out/bench.log 2>&1
 grep metric $out/bench.log | cut -c1-200
 python3 - "$out" <<'PY'
 import csv, glob, sys
