@@ -719,11 +719,19 @@ int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
     HIP_TRY(hipDeviceSynchronize());
     double acc[MR_N_KERNEL_TIMES] = {};
     uint64_t used = 0;
+    // only the slots that render the same kind of frame as the most recent one (same flags and
+    // row band) are averaged: a whole-frame mr_render on the library's stream must not be mixed
+    // into the statistics of band frames enqueued on the caller's streams
+    const mr_frame_desc &ref = sc->last->last_frame;
+    auto same_kind = [&](const FrameSlot &s) {
+        return s.have_frame && s.last_frame.flags == ref.flags && s.last_frame.row_begin == ref.row_begin &&
+               s.last_frame.row_end == ref.row_end;
+    };
     int active = 0;
-    for (auto &s : sc->slots) active += s->have_frame ? 1 : 0;
+    for (auto &s : sc->slots) active += same_kind(*s) ? 1 : 0;
     const uint64_t per_slot = std::max<uint64_t>(1, ((uint64_t)std::max(n_frames, 1) + active - 1) / std::max(active, 1));
     for (auto &s : sc->slots) {
-        if (!s->have_frame) continue;
+        if (!same_kind(*s)) continue;
         const bool light = (s->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
         const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(s->frames_enqueued, EVENT_RING), per_slot);
         for (uint64_t i = 0; i < n; ++i) {

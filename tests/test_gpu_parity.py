@@ -101,12 +101,12 @@ def test_errors_are_loud(api):
     scene.close()
 
 
-FULL = ["c2_diablo_1080p", "c3_diablo_floor_1080p", "c4_torus200k_1080p"]
+FULL = ["c2_diablo_1080p", "c3_diablo_floor_1080p", "c4_torus200k_1080p", "c5_torus1m_4k_skybox"]
 
 
 @pytest.mark.parametrize("name", FULL)
 def test_full_size_config_matches_reference_capture(api, oracle_mod, name):
-    """BASELINE.json configs 2-4 at 1920x1080 against what the reference itself rendered
+    """BASELINE.json configs 2-5 (1920x1080; c5: 1M triangles + skybox at 3840x2160) against what the reference itself rendered
     (uint8 frame, winner map, stencil and per-row sums of the z-buffer bit patterns are
     committed; the full float buffers are too large to commit, so they are checked against the
     oracle, which the CPU suite pins to the same captures)."""

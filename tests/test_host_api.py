@@ -16,7 +16,7 @@ from py_numpy_renderer_amd._pack import pack_scene
 from py_numpy_renderer_amd.plane_intersection import clipping, extract_frustum_planes
 
 
-@pytest.mark.parametrize("name", list(scenes.SMALL) + list(scenes.FULL))
+@pytest.mark.parametrize("name", list(scenes.SMALL) + list(scenes.FULL) + list(scenes.HUGE))
 def test_frame_constants_match_reference(api, name):
     g, _ = load_golden(name)
     f = pack_scene(scenes.build(api, name)).frame
