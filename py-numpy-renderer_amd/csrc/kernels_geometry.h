@@ -215,37 +215,19 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
 // (not just this device's band), stopping as soon as two are found:
 //   0 -> the reference returns CLIPPED for the face; 1 -> z = bar @ zlin is a dot (TF_SINGLE_Z).
 // Only the faces k_tri_setup could not settle itself arrive here (pixel boxes over 32 samples,
-// or a per-fragment clip test): small boxes are walked by one lane, the others are taken one at
-// a time by the whole wavefront, 64 samples per step, starting at the chunk with the centroid.
+// or a per-fragment clip test).
 __device__ __forceinline__ void
 tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
                const TriClip *__restrict__ clips, uint8_t *__restrict__ status, Counters *__restrict__ ctr,
                uint32_t block, uint32_t n_blocks)
 {
+    // one wavefront per listed face, 64 samples per step, starting at the chunk that holds the
+    // centroid (a well-shaped triangle is settled by that chunk alone)
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t n_count = ctr->n_count;
-  for (uint32_t i = block * blockDim.x + threadIdx.x; i - lane < n_count; i += n_blocks * blockDim.x) {
-    const bool valid = i < n_count;
-    const int f = valid ? (int)count_list[i] : 0;
-    TriRec t = {};
-    if (valid) t = tris[f];
-    const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
-    const int total = valid ? bw * bh : 0;
-    if (valid && total <= COUNT_SMALL_BOX) {
-        int found = 0;
-        unsigned int covered = 0;
-        for (int idx = 0; idx < total && found < 2; ++idx) {
-            bool cov;
-            found += sample_survives(fc, t, clips, t.x0 + idx % bw, t.y0 + idx / bw, cov) ? 1 : 0;
-            covered += cov ? 1u : 0u;
-        }
-        count_finish(tris, status, ctr, f, t.flags, found, covered);
-    }
-    unsigned long long big = __ballot(valid && total > COUNT_SMALL_BOX);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const int fb = __shfl(f, src);
+    const uint32_t waves = n_blocks * (blockDim.x / WAVE);
+    for (uint32_t i = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; i < n_count; i += waves) {
+        const int fb = (int)count_list[i];
         const TriRec tb = tris[fb];
         const int w = tb.x1 - tb.x0;
         const long long n = (long long)w * (tb.y1 - tb.y0);
@@ -264,7 +246,6 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
         }
         if (lane == 0) count_finish(tris, status, ctr, fb, tb.flags, found, covered);
     }
-  }
 }
 
 // Per-face result of the reference's lit pass (obj/triangular.py:101-112 with a stencil

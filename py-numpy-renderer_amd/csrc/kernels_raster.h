@@ -137,26 +137,31 @@ __device__ __forceinline__ void bin_emit(const FrameConst &fc, const BinArgs &a,
 // The same for a whole wavefront at once (every lane calls it, `want` says whether it has a
 // pair to emit).  Neighbouring triangles of a mesh fall into the same tile, and a tile's
 // counter is one L2 location: lanes with the same bin are combined into ONE atomic and share
-// out the returned range by rank, instead of queueing up to 64 deep on that location.
+// out the returned range by rank, instead of queueing up to 64 deep on that location.  The
+// groups are found first (ALU only), then every group leader issues its atomic in the same
+// instruction: one memory round trip however many different bins the wavefront touches.
 template <bool FILL>
 __device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArgs &a, bool want, int cls,
                                               uint32_t id, int tx, int ty)
 {
     const uint32_t bin = (uint32_t)cls * (uint32_t)(fc.tiles_x * fc.tiles_y) + (uint32_t)ty * fc.tiles_x + tx;
     const int lane = threadIdx.x & (WAVE - 1);
-    unsigned long long todo = __ballot(want);
+    unsigned long long todo = __ballot(want), mine = 0;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t lbin = (uint32_t)__shfl((int)bin, leader);
         const unsigned long long same = __ballot(want && bin == lbin) & todo;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&a.bin_count[lbin], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, leader);
-        if (FILL && ((same >> lane) & 1ull)) {
-            const uint32_t at = a.bin_offset[lbin] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            if (at < a.item_cap) a.items[at] = id;
-        }
+        if ((same >> lane) & 1ull) mine = same;
         todo &= ~same;
+    }
+    if (!want) mine = 0;
+    const int my_leader = mine ? __ffsll((long long)mine) - 1 : lane;
+    uint32_t base = 0;
+    if (mine && lane == my_leader) base = atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mine));
+    base = (uint32_t)__shfl((int)base, my_leader);
+    if (FILL && mine) {
+        const uint32_t at = a.bin_offset[bin] + base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+        if (at < a.item_cap) a.items[at] = id;
     }
 }
 
@@ -611,21 +616,22 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
 }
 
 // Sums the per-tile partial counts into the frame counters and counts the lit pixels (covered
-// and stencil == 0, compared as int16 like the reference's buffer); one workgroup, run only
-// when the statistics are asked for.
-__global__ void __launch_bounds__(1024)
+// and stencil == 0, compared as int16 like the reference's buffer); grid-stride over tiles and
+// pixels, one atomic per workgroup and counter; run only when the statistics are asked for.
+__global__ void __launch_bounds__(256)
 k_reduce_tile_stats(const FrameConst fc, const uint32_t *__restrict__ tile_stats, int n_tiles,
                     const int32_t *__restrict__ winner, const int32_t *__restrict__ stencil,
                     Counters *__restrict__ ctr)
 {
-    __shared__ unsigned long long part[TILE_STATS][1024 / WAVE];
+    __shared__ unsigned long long part[TILE_STATS][256 / WAVE];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + tid, gsz = (size_t)gridDim.x * blockDim.x;
     unsigned long long acc[TILE_STATS] = {};
-    for (int t = tid; t < n_tiles; t += blockDim.x)
+    for (size_t t = gid; t < (size_t)n_tiles; t += gsz)
 #pragma unroll
-        for (int k = 0; k < TILE_STATS - 1; ++k) acc[k] += tile_stats[(size_t)t * TILE_REC + k];
+        for (int k = 0; k < TILE_STATS - 1; ++k) acc[k] += tile_stats[t * TILE_REC + k];
     const size_t p0 = (size_t)fc.band_y0 * fc.width, p1 = (size_t)fc.band_y1 * fc.width;
-    for (size_t p = p0 + tid; p < p1; p += blockDim.x)
+    for (size_t p = p0 + gid; p < p1; p += gsz)
         acc[4] += (winner[p] >= 0 && (int16_t)stencil[p] == 0) ? 1u : 0u;
 #pragma unroll
     for (int k = 0; k < TILE_STATS; ++k) {
@@ -636,10 +642,10 @@ k_reduce_tile_stats(const FrameConst fc, const uint32_t *__restrict__ tile_stats
     __syncthreads();
     if (tid < TILE_STATS) {
         unsigned long long v = 0;
-        for (int w = 0; w < 1024 / WAVE; ++w) v += part[tid][w];
+        for (int w = 0; w < 256 / WAVE; ++w) v += part[tid][w];
         unsigned long long *dst = tid == 0 ? &ctr->frag_tri : tid == 1 ? &ctr->frag_quad
                                 : tid == 2 ? &ctr->stencil_updates : tid == 3 ? &ctr->covered_px : &ctr->lit_px;
-        atomicAdd(dst, v);
+        if (v) atomicAdd(dst, v);
     }
 }
 

@@ -347,7 +347,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     {
         // silhouette detection and the leftover survivor counts are independent: one launch
         const unsigned sil_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, 256) : 0u;
-        const unsigned count_blocks = fc.n_faces > 0 ? std::min(64u, blocks_for(fc.n_faces, 256)) : 0u;
+        const unsigned count_blocks = fc.n_faces > 0 ? std::min(128u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
         if (sil_blocks + count_blocks > 0)
             hipLaunchKernelGGL(k_silhouette_and_count, dim3(sil_blocks + count_blocks), dim3(256), 0, stream, fc,
                                sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
@@ -432,7 +432,7 @@ int fetch_counters(mr_scene *sc, FrameSlot *fs)
     Counters *ctr = fs->d_counters.as<Counters>();
     if (!fs->stats_reduced) {
         const FrameConst fc = make_const(sc, &fs->last_frame);
-        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, fs->stream, fc, fs->d_tile_stats.as<uint32_t>(),
+        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(512), dim3(256), 0, fs->stream, fc, fs->d_tile_stats.as<uint32_t>(),
                            fs->last_n_tiles, fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(), ctr);
         fs->stats_reduced = true;
     }
