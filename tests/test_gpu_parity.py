@@ -166,3 +166,71 @@ def test_face_status_and_stdout_match_reference(api, capsys, name):
     scene.render(shadows=shadows)
     assert capsys.readouterr().out == meta["stdout"]
     scene.close()
+
+
+def _against_oracle(api, oracle_mod, scene, shadows=True, label=""):
+    backend = scene._backend()
+    out = backend.render(scene, shadows=shadows, keep_float=True)
+    want = oracle_mod.render(scene, shadows=shadows)
+    _assert_buffers(backend, out, want.z, want.winner, want.stencil, want.frame, want.out, label)
+    return out, want
+
+
+def test_edge_cases_against_oracle(api, oracle_mod):
+    """Empty scene, everything off screen, 1x1 and odd-sized frames, several models, faces cut by
+    the screen border, a face exactly filling one pixel box."""
+    cam, dbg = scenes._std_cameras(api)
+    empty = scenes._scene(api, cam, dbg, scenes._std_light(api), (9, 13), [])
+    out, want = _against_oracle(api, oracle_mod, empty, label="empty scene")
+    assert (want.winner == -1).all()
+    empty.close()
+
+    cam, dbg = scenes._std_cameras(api)
+    far_away = scenes._floor(api, textured=False) @ api.translation((100.0, 0.0, 0.0))
+    off = scenes._scene(api, cam, dbg, scenes._std_light(api), (33, 47), [far_away])
+    _against_oracle(api, oracle_mod, off, label="off screen")
+    off.close()
+
+    for res in ((1, 1), (7, 5), (17, 31), (250, 333)):
+        cam, dbg = scenes._std_cameras(api)
+        cube = api.Model.load_model(__import__("os").path.join(scenes.ASSETS, "cube", "cube.obj"))
+        cube.normals = -cube.normals
+        sc = scenes._scene(api, cam, dbg, scenes._std_light(api), res, [cube @ api.scale(0.7), scenes._floor(api)])
+        _against_oracle(api, oracle_mod, sc, label=f"resolution {res}")
+        sc.close()
+
+    # three models, one of them the same mesh twice (coincident surfaces: every z ties, later face wins)
+    cam, dbg = scenes._std_cameras(api)
+    a, b = scenes._floor(api), scenes._floor(api, textured=False)
+    tet = api.Model.load_model(scenes.bare_tetra_obj())
+    sc = scenes._scene(api, cam, dbg, scenes._std_light(api), (96, 128), [a, tet, b])
+    out, want = _against_oracle(api, oracle_mod, sc, label="coincident models")
+    n_first = len(a._faces) + len(tet._faces)
+    assert (want.winner[(want.winner >= 0) & (want.winner != 2) & (want.winner != 3) & (want.winner != 4) & (want.winner != 5)] >= n_first).all()
+    sc.close()
+
+
+def test_spot_and_directional_lights_full_pipeline(api, oracle_mod):
+    for kind in (api.Lightning.SPOT_LIGHTNING, api.Lightning.DIRECTIONAL_LIGHTNING):
+        cam, dbg = scenes._std_cameras(api)
+        light = api.Light((2, 3, 4), light_type=kind, ambient_strength=0.1, specular_strength=0.3)
+        sc = scenes._scene(api, cam, dbg, light, (150, 200), [scenes._torus(api, 24, 16), scenes._floor(api)])
+        _against_oracle(api, oracle_mod, sc, label=str(kind))
+        sc.close()
+
+
+def test_scene_changes_are_picked_up(api, oracle_mod):
+    """Adding a model, moving one (Model @ M) and registering a texture all re-upload the scene."""
+    cam, dbg = scenes._std_cameras(api)
+    floor = scenes._floor(api, textured=False)
+    sc = scenes._scene(api, cam, dbg, scenes._std_light(api), (90, 120), [floor])
+    first = sc.render()
+    sc.add_model(api.Model.load_model(scenes.bare_tetra_obj()))
+    second = sc.render()
+    assert not np.array_equal(first, second)
+    _against_oracle(api, oracle_mod, sc, label="after add_model")
+    sc.models[1] = sc.models[1] @ api.translation((0.3, 0.2, 0.0))
+    _against_oracle(api, oracle_mod, sc, label="after Model @ M")
+    floor.textures.register("diffuse", __import__("os").path.join(scenes.ASSETS, "floor_diffuse.tga"), normalize=False)
+    _against_oracle(api, oracle_mod, sc, label="after texture register")
+    sc.close()
