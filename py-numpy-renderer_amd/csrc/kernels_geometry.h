@@ -1,6 +1,7 @@
 // kernels_geometry.h -- per-vertex, per-face and per-silhouette-edge work of one frame.
 //
-//   k_vertex      obj/triangular.py:36-45  (once per unique vertex instead of per face corner)
+//   k_vertex      obj/triangular.py:36-45  (once per unique vertex instead of per face corner);
+//                 k_vertex_mfma does the same on the matrix cores (default), bit-identical
 //   k_tri_setup   obj/triangular.py:47-78, obj/core.py:127-136, obj/transformation.py:12-43
 //   k_tri_count   how many fragments of a face survive coverage + clip (decides NumPy's
 //                 dot-vs-gemv rounding of z, and the CLIPPED status)
@@ -48,6 +49,71 @@ k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__res
     o.pad = 0;
     out[i] = o;
     out_clip[i] = oc;
+}
+
+// The same vertex stage on the matrix cores.  The two products of obj/triangular.py:36-45
+// (v @ [MVP | debug MVP] and ndc @ viewport) are dense 16x4 by 4x16 contractions per 16
+// vertices, i.e. exactly one v_mfma_f64_16x16x4_f64 each.  Measured on MI355X
+// (tools/micro/mfma_vertex_check.hip, 8.4 M outputs): that instruction accumulates k = 0..3 in
+// order with one rounding per step, bit-identical to the ascending fma chain the reference's
+// BLAS uses, so the result is the same VertexOut / VertexClip as k_vertex's, bit for bit.
+// One wavefront = 16 vertices.  Operand layout (cdna_hip_programming.md section 3): A lane l holds
+// A[row l%16][k l/16], B lane l holds B[k l/16][col l%16], D register i of lane l holds
+// D[row (l>>4) + 4i][col l&15]; the D -> A re-layout between the two products goes through LDS.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
+              VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr)
+{
+    __shared__ double s_clip[4][16][8];     // per wavefront: [vertex][MVP x,y,z,w | debug x,y,z,w]
+    __shared__ double s_scr[4][16][4];      // per wavefront: [vertex][screen x, y, z]
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr = Counters{};   // first kernel of the frame
+    const int base = (blockIdx.x * (blockDim.x / WAVE) + wv) * 16;
+    const int row = lane & 15, k = lane >> 4;
+    const bool have = base + row < fc.n_vertices;
+
+    // clip = v @ [MVP | debug MVP]
+    const double a = have ? verts[(size_t)(base + row) * 4 + k] : 0.0;
+    const double b = row < 4 ? fc.mvp[k * 4 + row] : (row < 8 ? fc.debug_mvp[k * 4 + row - 4] : 0.0);
+    mfma_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    if (row < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_clip[wv][k + 4 * i][row] = acc[i];
+    }
+    __syncthreads();
+
+    // ndc = clip * (1 / clip.w);  screen = ndc @ viewport
+    const double depth = 1.0 / s_clip[wv][row][3];
+    const double ndc = s_clip[wv][row][k] * depth;
+    const double b2 = row < 4 ? fc.viewport[k * 4 + row] : 0.0;
+    mfma_d4 acc2 = { 0.0, 0.0, 0.0, 0.0 };
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ndc, b2, acc2, 0, 0, 0);
+    if (row < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_scr[wv][k + 4 * i][row] = acc2[i];
+    }
+    __syncthreads();
+
+    if (lane < 16 && base + lane < fc.n_vertices) {
+        const int v = lane;
+        VertexOut o;
+        VertexClip oc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { oc.clip[j] = s_clip[wv][v][j]; oc.clipd[j] = s_clip[wv][v][4 + j]; }
+        o.sx = s_scr[wv][v][0]; o.sy = s_scr[wv][v][1]; o.sz = s_scr[wv][v][2];
+        o.depth = 1.0 / oc.clip[3];
+        o.zlin = linearize_z(fc, o.sz);
+        const double kk = 1.0 - 1e-12;                  // "safely inside" flag: see k_vertex
+        const double wl = oc.clip[3] * kk, wd = oc.clipd[3] * kk;
+        o.safe = (fabs(oc.clip[0]) < wl && fabs(oc.clip[1]) < wl && fabs(oc.clip[2]) < wl &&
+                  fabs(oc.clipd[0]) < wd && fabs(oc.clipd[1]) < wd && fabs(oc.clipd[2]) < wd) ? 1 : 0;
+        o.pad = 0;
+        out[base + v] = o;
+        out_clip[base + v] = oc;
+    }
 }
 
 // unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130),

@@ -180,7 +180,7 @@ __device__ __forceinline__ void sky_color(const FrameConst &fc, const uint8_t *s
 
 __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v); }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_shade(const FrameConst fc, const ShadeArgs a)
 {
     // one workgroup per 16x16 pixel tile (the visibility kernel's tiles): neighbouring pixels
