@@ -182,15 +182,16 @@ __device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, Coun
 
 constexpr int COUNT_SMALL_BOX = 32;   // pixel boxes up to this size are walked by a single lane
 
-__global__ void __launch_bounds__(256)
-k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
-            const double *__restrict__ verts, const VertexOut *__restrict__ vout,
-            const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris, TriClip *__restrict__ clips,
-            uint8_t *__restrict__ status, uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list,
-            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr)
+// One face: status, TriRec / TriClip, light-facing flag.  Returns bit 0 = the face goes on to
+// the visibility kernel, bit 1 = its survivor count is left to k_tri_count; `covered` receives
+// the fragments of a face settled as CLIPPED right here.
+__device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const int32_t *__restrict__ faces,
+                                             const uint8_t *__restrict__ face_flags, const double *__restrict__ verts,
+                                             const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip,
+                                             TriRec *__restrict__ tris, TriClip *__restrict__ clips,
+                                             uint8_t *__restrict__ status, uint8_t *__restrict__ lit,
+                                             unsigned int &covered)
 {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= fc.n_faces) return;
     const int32_t *fcx = faces + (size_t)f * 12;
     const int va = fcx[0], vb = fcx[4], vc = fcx[8];
     const uint8_t ff = face_flags[f];
@@ -209,7 +210,7 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
                         e0[0] * e1[1] - e0[1] * e1[0] };
         double u[3];
         normalize3(n, u);
-        if (u[2] < 0) { status[f] = FACE_BACK_FACE_CULLING; return; }
+        if (u[2] < 0) { status[f] = FACE_BACK_FACE_CULLING; return 0; }
     }
 
     TriRec t;
@@ -217,7 +218,7 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     int bx0, bx1, by0, by1;
     if (!bound_box(xs, ys, 3, fc.width, fc.height, bx0, bx1, by0, by1)) {
         status[f] = FACE_EMPTY_Z;
-        return;
+        return 0;
     }
     t.x0 = (int16_t)bx0; t.x1 = (int16_t)bx1; t.y0 = (int16_t)by0; t.y1 = (int16_t)by1;
     t.ax = A.sx; t.ay = A.sy;
@@ -227,16 +228,16 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     t.d01 = (float)chain2(t.v0x, t.v0y, t.v1x, t.v1y);
     t.d11 = (float)chain2(t.v1x, t.v1y, t.v1x, t.v1y);
     float den = t.d00 * t.d11 - t.d01 * t.d01;
-    if (den == 0) { status[f] = FACE_EMPTY_B; return; }
+    if (den == 0) { status[f] = FACE_EMPTY_B; return 0; }
     t.inv_den = 1.0f / den;
     t.zl0 = A.zlin; t.zl1 = B.zlin; t.zl2 = C.zlin;
     t.pad[0] = t.pad[1] = 0;
     long long box = (long long)(bx1 - bx0) * (long long)(by1 - by0);
     const bool need_clip = (ff & FF_CLIP) && !(A.safe && B.safe && C.safe);
-    t.flags = (need_clip ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u);
+    t.flags = (need_clip ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u) | ((uint32_t)ff << 8);   // bits 8-15: face flags, for k_shade
     t.face = f;
+    if (box <= 0) { status[f] = FACE_CLIPPED; return 0; }    // no sample inside the box
     status[f] = FACE_OK;
-    if (box <= 0) { status[f] = FACE_CLIPPED; return; }    // no sample inside the box
 
     // How many fragments survive coverage + clip (0 -> CLIPPED, 1 -> z is a dot, TF_SINGLE_Z)?
     // A small pixel box that needs no clip test is settled right here, by this lane, over the
@@ -245,17 +246,16 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     if (count_here) {
         const int bw = bx1 - bx0;
         int found = 0;
-        unsigned int covered = 0;
         for (int idx = 0; idx < (int)box && found < 2; ++idx) {
             bool cov;
             found += sample_survives(fc, t, nullptr, bx0 + idx % bw, by0 + idx / bw, cov) ? 1 : 0;
             covered += cov ? 1u : 0u;
         }
         if (found == 0) {
-            status[f] = FACE_CLIPPED;              // never reaches the visibility kernel: count its fragments here
-            if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
-            return;
+            status[f] = FACE_CLIPPED;              // never reaches the visibility kernel: its fragments are counted here
+            return 0;
         }
+        covered = 0;
         if (found == 1) t.flags |= TF_SINGLE_Z;
     }
     tris[f] = t;
@@ -269,12 +269,51 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
             cl.clipd[0][j] = ca.clipd[j]; cl.clipd[1][j] = cb.clipd[j]; cl.clipd[2][j] = cc.clipd[j];
         }
     }
-    uint32_t slot = atomicAdd(&ctr->n_valid_tris, 1u);
-    valid_list[slot] = (uint32_t)f;
-    if (!count_here) {
-        slot = atomicAdd(&ctr->n_count, 1u);
-        count_list[slot] = (uint32_t)f;
+    return count_here ? 1 : 3;
+}
+
+constexpr int SETUP_BLOCK = 512;
+
+// The two face lists (valid_list: faces to bin; count_list: faces k_tri_count still has to
+// settle) are appended to with ONE atomic per workgroup and list: the frame's counters share a
+// cache line, and same-line atomics retire at only ~0.3 per ns on MI355X
+// (tools/micro/atomic_bench.hip), so per-wavefront appends alone cost more than the set-up.
+__global__ void __launch_bounds__(SETUP_BLOCK)
+k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
+            const double *__restrict__ verts, const VertexOut *__restrict__ vout,
+            const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris, TriClip *__restrict__ clips,
+            uint8_t *__restrict__ status, uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list,
+            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr)
+{
+    constexpr int NW = SETUP_BLOCK / WAVE;
+    __shared__ uint32_t s_valid[NW], s_count[NW], s_covered;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    if (threadIdx.x == 0) s_covered = 0;
+    unsigned int covered = 0;
+    const int r = f < fc.n_faces ? tri_setup_one(fc, f, faces, face_flags, verts, vout, vclip, tris, clips,
+                                                 status, lit, covered)
+                                 : 0;
+    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);
+    if (lane == 0) { s_valid[wv] = (uint32_t)__popcll(bv); s_count[wv] = (uint32_t)__popcll(bc); }
+    __syncthreads();
+    if (covered) atomicAdd(&s_covered, covered);
+    if (threadIdx.x == 0) {
+        uint32_t nv = 0, nc = 0;
+        for (int w = 0; w < NW; ++w) { nv += s_valid[w]; nc += s_count[w]; }
+        uint32_t bvb = nv ? atomicAdd(&ctr->n_valid_tris, nv) : 0u;
+        uint32_t bcb = nc ? atomicAdd(&ctr->n_count, nc) : 0u;
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t a = s_valid[w], b = s_count[w];
+            s_valid[w] = bvb; s_count[w] = bcb;
+            bvb += a; bcb += b;
+        }
     }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (r & 1) valid_list[s_valid[wv] + (uint32_t)__popcll(bv & below)] = (uint32_t)f;
+    if (r & 2) count_list[s_count[wv] + (uint32_t)__popcll(bc & below)] = (uint32_t)f;
+    if (threadIdx.x == 0 && s_covered) atomicAdd(&ctr->frag_tri, (unsigned long long)s_covered);
 }
 
 // Counts, per set-up triangle, the fragments that survive coverage + clip over the WHOLE frame

@@ -272,65 +272,84 @@ k_bin_fill(const FrameConst fc, const BinArgs a, uint32_t classify_blocks, uint3
     else bin_classify_body<true>(fc, a, blockIdx.x - large_blocks);
 }
 
-// Exclusive scan of the BIN_CLASSES * n_tiles bin counts by one workgroup of 1024 threads,
-// 24 coalesced rows of 1024 counts per round; zeroes the counts (the fill pass reuses them as
-// cursors), records the per-class totals and flags overflow of the item array.
-__global__ void __launch_bounds__(1024)
+// Exclusive scan of the BIN_CLASSES * n_tiles bin counts; zeroes the counts (the fill pass
+// reuses them as cursors), records the totals and flags overflow of the item array.
+// Single pass over many workgroups: each one scans 1024 counts (one uint4 per thread),
+// publishes its total tagged with the frame's epoch, and reads the totals of all the
+// workgroups before it in one go -- one lane per predecessor -- instead of waiting for a
+// chained prefix.  A workgroup only ever waits for lower-numbered ones, which are dispatched
+// first, so the wait always ends; the epoch tag means the slots never need clearing.
+constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = SCAN_BLOCK * 4;
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
 k_scan_bins(uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_offset, int n_tiles,
-            uint32_t item_cap, Counters *__restrict__ ctr)
+            uint32_t item_cap, Counters *__restrict__ ctr, unsigned long long *__restrict__ partials,
+            uint32_t epoch)
 {
-    // 24 rows: the 3 x 8 160 bins of a 1920x1080 frame are scanned in a single round, with all
-    // of a thread's loads in flight at once (one workgroup cannot hide latency any other way)
-    constexpr int ROWS = 24, NT = 1024, NW = NT / WAVE;
-    __shared__ uint32_t wave_sum[ROWS][NW];
+    constexpr int NW = SCAN_BLOCK / WAVE;
+    __shared__ uint32_t s_wave[NW], s_before;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int n = BIN_CLASSES * n_tiles;
-    uint32_t carry = 0;
-    for (int base = 0; base < n; base += ROWS * NT) {
-        uint32_t v[ROWS], inc[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int i = base + r * NT + tid;
-            v[r] = i < n ? bin_count[i] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            uint32_t x = v[r];
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const uint32_t y = __shfl_up(x, off);
-                if (lane >= off) x += y;
-            }
-            inc[r] = x;
-            if (lane == WAVE - 1) wave_sum[r][wv] = x;
-        }
-        __syncthreads();
-        uint32_t row_prefix = 0;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            uint32_t before = 0, row_total = 0;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) {
-                const uint32_t s = wave_sum[r][k];
-                before += k < wv ? s : 0u;
-                row_total += s;
-            }
-            const int i = base + r * NT + tid;
-            if (i < n) {
-                bin_offset[i] = carry + row_prefix + before + inc[r] - v[r];
-                bin_count[i] = 0;
-            }
-            row_prefix += row_total;
-        }
-        carry += row_prefix;
-        __syncthreads();
+    const int n = BIN_CLASSES * n_tiles, b = (int)blockIdx.x;
+    const int i0 = b * SCAN_ITEMS + tid * 4;
+
+    uint32_t v[4] = { 0u, 0u, 0u, 0u };
+    if (i0 + 3 < n) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(bin_count + i0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        for (int j = 0; j < 4; ++j) v[j] = i0 + j < n ? bin_count[i0 + j] : 0u;
     }
-    if (tid == 0) {
-        bin_offset[n] = carry;
-        const uint32_t tri_total = bin_offset[2 * n_tiles];   // written above by this workgroup
-        ctr->tri_bin_total = tri_total;
-        ctr->quad_bin_total = carry - tri_total;
-        if (carry > item_cap) atomicOr(&ctr->overflow, 1u);
+    const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t y = __shfl_up(inc, off);
+        if (lane >= off) inc += y;
+    }
+    if (lane == WAVE - 1) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, block_total = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const uint32_t s = s_wave[k];
+        before += k < wv ? s : 0u;
+        block_total += s;
+    }
+    if (tid == 0)
+        __hip_atomic_store(&partials[b], ((unsigned long long)epoch << 32) | block_total, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (wv == 0) {
+        uint32_t sum = 0;
+        for (int k = lane; k < b; k += WAVE) {
+            unsigned long long p;
+            do {
+                p = __hip_atomic_load(&partials[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((uint32_t)(p >> 32) != epoch);
+            sum += (uint32_t)p;
+        }
+#pragma unroll
+        for (int off = WAVE / 2; off; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) s_before = sum;
+    }
+    __syncthreads();
+    const uint32_t base = s_before + before + inc - mine;
+    const uint32_t o[4] = { base, base + v[0], base + v[0] + v[1], base + v[0] + v[1] + v[2] };
+    if (i0 + 3 < n) {
+        *reinterpret_cast<uint4 *>(bin_offset + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4 *>(bin_count + i0) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) { bin_offset[i0 + j] = o[j]; bin_count[i0 + j] = 0u; }
+    }
+    // the triangle classes end where the quad class begins
+    const int split = 2 * n_tiles;
+    if (split >= i0 && split < i0 + 4 && split < n) ctr->tri_bin_total = o[split - i0];
+    if (b == (int)gridDim.x - 1 && tid == 0) {
+        const uint32_t total = s_before + block_total;
+        bin_offset[n] = total;
+        ctr->bin_total = total;
+        if (n_tiles == 0 || split >= n) ctr->tri_bin_total = total;
+        if (total > item_cap) atomicOr(&ctr->overflow, 1u);
     }
 }
 
@@ -556,27 +575,60 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
 #pragma unroll
         for (int i = 0; i < 4; ++i) me[i] = mq->e[i];
 
+        // Lane j classifies ITS quad against this wavefront's 16x4 pixel strip with the same
+        // corner argument as quad_touches_tile: per edge, the rounded cross product is monotone
+        // in x and in y, so over the strip it is extreme at a corner.  No corner on the inner
+        // side of some edge -> no sample of the strip is inside (skip the quad: most of a
+        // tile's quads miss most of its strips); all four corners on the inner side of every
+        // edge -> every sample is inside (skip the per-pixel edge tests).  Exact, no margins.
+        bool q_reject = lane >= n, q_accept = !q_reject && (m_nf & 0xff) <= 4;
+        {
+            const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
+            const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
+            const bool m_front = (m_nf & 0x100) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < 3 || (m_nf & 0xff) > 3) {
+                    const double px0 = (xa - me[i].sx) * me[i].ey, px1 = (xb - me[i].sx) * me[i].ey;
+                    const double py0 = (ya - me[i].sy) * me[i].ex, py1 = (yb - me[i].sy) * me[i].ex;
+                    const double c00 = px0 - py0, c10 = px1 - py0, c01 = px0 - py1, c11 = px1 - py1;
+                    const bool any = m_front ? (c00 > 0 || c10 > 0 || c01 > 0 || c11 > 0)
+                                             : (c00 < 0 || c10 < 0 || c01 < 0 || c11 < 0);
+                    const bool all = m_front ? (c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0)
+                                             : (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0);
+                    q_reject = q_reject || !any;
+                    q_accept = q_accept && all;
+                }
+            }
+        }
+        unsigned long long todo = __ballot(!q_reject);
+        const unsigned long long accepted = __ballot(q_accept);
+
         int sten = 0;
         unsigned int qfrags = 0, qupd = 0;
-        for (int j = 0; j < n; ++j) {
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
             const int bx = bcast(m_bx, j), by = bcast(m_by, j), nf = bcast(m_nf, j);
             const bool front = (nf & 0x100) != 0;
             const int nv = nf & 0xff;
             bool in = live && px >= (bx & 0xffff) && px < (bx >> 16) && py >= (by & 0xffff) && py < (by >> 16);
+            if (!((accepted >> j) & 1)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < 3 || nv > 3) {
-                    const double ax = dpx - bcast(me[i].sx, j), ay = dpy - bcast(me[i].sy, j);
-                    const double cr = ax * bcast(me[i].ey, j) - ay * bcast(me[i].ex, j);
-                    in = in && (front ? cr > 0 : cr < 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (i < 3 || nv > 3) {
+                        const double ax = dpx - bcast(me[i].sx, j), ay = dpy - bcast(me[i].sy, j);
+                        const double cr = ax * bcast(me[i].ey, j) - ay * bcast(me[i].ex, j);
+                        in = in && (front ? cr > 0 : cr < 0);
+                    }
                 }
-            }
-            if (nv > 4) {                           // clipped polygons with 5+ vertices are rare
-                const QuadRec *q = quads + bcast((int)myid, j);
-                for (int i = 4; i < nv; ++i) {
-                    const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
-                    const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
-                    in = in && (front ? cr > 0 : cr < 0);
+                if (nv > 4) {                           // clipped polygons with 5+ vertices are rare
+                    const QuadRec *q = quads + bcast((int)myid, j);
+                    for (int i = 4; i < nv; ++i) {
+                        const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
+                        const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
+                        in = in && (front ? cr > 0 : cr < 0);
+                    }
                 }
             }
             const unsigned long long m = __ballot(in);

@@ -25,6 +25,7 @@ struct ShadeArgs {
     const int32_t *winner;
     const int32_t *stencil;    // 32-bit accumulator; the reference's buffer is its low 16 bits
     const uint8_t *sky;        // cubemap texels (6, S, S, 3) or null
+    const float *gamma_lut;    // GAMMA_LUT_SIZE thresholds of the finalise step function
     float *frame;          // optional float frame (row = screen y), may be null
     uint8_t *out;          // band of the final frame, row 0 = top row of the band
 };
@@ -73,43 +74,52 @@ __device__ __forceinline__ void c_normalize3(const double a[3], double o[3])
     o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
 }
 
-// 3x3 inverse by LU with partial pivoting (np.linalg.inv -> LAPACK gesv)
-__device__ bool inv3(const double a[3][3], double inv[3][3])
+// 3x3 inverse by LU with partial pivoting (np.linalg.inv -> LAPACK gesv).  Rows are swapped
+// by value, never indexed dynamically, so everything stays in registers.
+__device__ __forceinline__ void swap_rows(bool c, double x[3], double y[3], int &px, int &py)
 {
-    double lu[3][3];
-    int perm[3] = { 0, 1, 2 };
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lu[i][j] = a[i][j];
 #pragma unroll
-    for (int col = 0; col < 3; ++col) {
-        int piv = col;
-        double best = fabs(lu[col][col]);
-        for (int r = col + 1; r < 3; ++r)
-            if (fabs(lu[r][col]) > best) { best = fabs(lu[r][col]); piv = r; }
-        if (best == 0) return false;
-        if (piv != col) {
-            for (int j = 0; j < 3; ++j) { double t = lu[col][j]; lu[col][j] = lu[piv][j]; lu[piv][j] = t; }
-            int t = perm[col]; perm[col] = perm[piv]; perm[piv] = t;
-        }
-        const double r = c_rcp(lu[col][col]);
-        for (int i = col + 1; i < 3; ++i) {
-            lu[i][col] *= r;
-            for (int j = col + 1; j < 3; ++j) lu[i][j] = fma(-lu[i][col], lu[col][j], lu[i][j]);
-        }
+    for (int j = 0; j < 3; ++j) { const double t = x[j]; x[j] = c ? y[j] : x[j]; y[j] = c ? t : y[j]; }
+    const int t = px; px = c ? py : px; py = c ? t : py;
+}
+__device__ __forceinline__ bool inv3(const double a[3][3], double inv[3][3])
+{
+    double r0[3] = { a[0][0], a[0][1], a[0][2] }, r1[3] = { a[1][0], a[1][1], a[1][2] },
+           r2[3] = { a[2][0], a[2][1], a[2][2] };
+    int p0 = 0, p1 = 1, p2 = 2;
+    // column 0: first row of maximal |.| (idamax)
+    {
+        const bool one = fabs(r1[0]) > fabs(r0[0]);
+        const double best = one ? fabs(r1[0]) : fabs(r0[0]);
+        const bool two = fabs(r2[0]) > best;
+        if ((two ? fabs(r2[0]) : best) == 0) return false;
+        swap_rows(one && !two, r0, r1, p0, p1);
+        swap_rows(two, r0, r2, p0, p2);
+        const double r = c_rcp(r0[0]);
+        r1[0] *= r; r2[0] *= r;
+        r1[1] = fma(-r1[0], r0[1], r1[1]); r1[2] = fma(-r1[0], r0[2], r1[2]);
+        r2[1] = fma(-r2[0], r0[1], r2[1]); r2[2] = fma(-r2[0], r0[2], r2[2]);
     }
-    const double rd[3] = { c_rcp(lu[0][0]), c_rcp(lu[1][1]), c_rcp(lu[2][2]) };
+    {
+        const bool two = fabs(r2[1]) > fabs(r1[1]);
+        if ((two ? fabs(r2[1]) : fabs(r1[1])) == 0) return false;
+        swap_rows(two, r1, r2, p1, p2);
+        const double r = c_rcp(r1[1]);
+        r2[1] *= r;
+        r2[2] = fma(-r2[1], r1[2], r2[2]);
+    }
+    if (fabs(r2[2]) == 0) return false;
+    const double rd0 = c_rcp(r0[0]), rd1 = c_rcp(r1[1]), rd2 = c_rcp(r2[2]);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        double y[3];
-        for (int i = 0; i < 3; ++i) {
-            double s = (perm[i] == j) ? 1.0 : 0.0;
-            for (int k = 0; k < i; ++k) s = fma(-lu[i][k], y[k], s);
-            y[i] = s;
-        }
-        for (int i = 2; i >= 0; --i) {
-            double s = y[i];
-            for (int k = i + 1; k < 3; ++k) s = fma(-lu[i][k], inv[k][j], s);
-            inv[i][j] = s * rd[i];
-        }
+        // L y = P e_j, then U x = y
+        const double y0 = p0 == j ? 1.0 : 0.0;
+        const double y1 = fma(-r1[0], y0, p1 == j ? 1.0 : 0.0);
+        const double y2 = fma(-r2[1], y1, fma(-r2[0], y0, p2 == j ? 1.0 : 0.0));
+        const double x2 = y2 * rd2;
+        const double x1 = fma(-r1[2], x2, y1) * rd1;
+        const double x0 = fma(-r0[2], x2, fma(-r0[1], x1, y0)) * rd0;
+        inv[0][j] = x0; inv[1][j] = x1; inv[2][j] = x2;
     }
     return true;
 }
@@ -161,10 +171,10 @@ __device__ __forceinline__ void sky_color(const FrameConst &fc, const uint8_t *s
         for (int j = 0; j < 3; ++j) ray[j] = chain3((double)u, (double)v, (double)w, r[j], r[3 + j], r[6 + j]);
         // CubeMap.__getitem__: major axis (first maximum of |.|), the other two components / it
         int major = 0;
-        if (fabs(ray[1]) > fabs(ray[major])) major = 1;
-        if (fabs(ray[2]) > fabs(ray[major])) major = 2;
-        const double amp = ray[major];
-        const double c0 = ray[major == 0 ? 1 : 0], c1 = ray[major == 2 ? 1 : 2];
+        double amp = ray[0];
+        if (fabs(ray[1]) > fabs(amp)) { major = 1; amp = ray[1]; }
+        if (fabs(ray[2]) > fabs(amp)) { major = 2; amp = ray[2]; }
+        const double c0 = major == 0 ? ray[1] : ray[0], c1 = major == 2 ? ray[1] : ray[2];
         const double n0 = (c0 / amp + 1) / 2, n1 = (c1 / amp + 1) / 2;
         const int side = (amp < 0 ? 1 : 0) + 2 * major;
         long long i0 = (long long)(n0 * (double)S - 1), i1 = (long long)(n1 * (double)S - 1);
@@ -178,6 +188,23 @@ __device__ __forceinline__ void sky_color(const FrameConst &fc, const uint8_t *s
     }
 }
 
+constexpr int GAMMA_LUT_SIZE = 257;
+
+// uint8(x ** 0.8 * 255) of obj/core.py:640.  For 0 <= x <= 1 the step is located with the
+// hardware log2 / exp2 (a few ulp, i.e. never off by more than one step) and then settled
+// against the two neighbouring thresholds, which were derived from powf itself: same result
+// as the ~60-instruction powf, in about ten.  Anything else (NaN, negative, > 1: only a
+// caller-supplied background can be) takes powf.
+__device__ __forceinline__ uint8_t gamma_u8(float x, const float *lut)
+{
+    if (!(x >= 0.0f && x <= 1.0f)) return (uint8_t)(powf(x, 0.8f) * 255.0f);
+    const float approx = __builtin_amdgcn_exp2f(0.8f * __builtin_amdgcn_logf(x));
+    int k = min(max((int)(approx * 255.0f), 0), 255);
+    k += x >= lut[k + 1] ? 1 : 0;
+    k -= x < lut[k] ? 1 : 0;
+    return (uint8_t)k;
+}
+
 __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v); }
 
 __global__ void __launch_bounds__(256, 2)
@@ -185,6 +212,10 @@ k_shade(const FrameConst fc, const ShadeArgs a)
 {
     // one workgroup per 16x16 pixel tile (the visibility kernel's tiles): neighbouring pixels
     // share winners, so the gathers of records, attributes and texels stay in a few cache lines
+    __shared__ float s_gamma[GAMMA_LUT_SIZE];
+    s_gamma[threadIdx.x] = a.gamma_lut[threadIdx.x];
+    if (threadIdx.x == 0) s_gamma[GAMMA_LUT_SIZE - 1] = a.gamma_lut[GAMMA_LUT_SIZE - 1];
+    __syncthreads();
     const int W = fc.width;
     const int tile = (int)blockIdx.x;
     const int px = (tile % fc.tiles_x) * TILE_W + ((int)threadIdx.x & (TILE_W - 1));
@@ -360,7 +391,7 @@ k_shade(const FrameConst fc, const ShadeArgs a)
     const int out_row = fc.band_y1 - 1 - py;
     uint8_t *o = a.out + ((size_t)out_row * W + px) * 3;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) o[j] = (uint8_t)(powf(rgb[j], 0.8f) * 255.0f);
+    for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
 }
 
 }  // namespace mr

@@ -87,7 +87,7 @@ constexpr int EVENT_RING = 64, N_MARKS = 10;
 struct FrameSlot {
     hipStream_t stream = nullptr;                 // the stream this slot serves
     DevBuf d_vout, d_vclip, d_tris, d_clips, d_status, d_lit, d_valid, d_count_list, d_quads, d_sil, d_counters;
-    DevBuf d_bin_count, d_bin_offset, d_items, d_work, d_quad_work, d_tile_stats;
+    DevBuf d_bin_count, d_bin_offset, d_scan_part, d_items, d_work, d_quad_work, d_tile_stats;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
     uint32_t item_cap = 0, work_cap = 0, quad_cap = 0, quad_work_cap = 0;
     int bins_zeroed_for = 0;
@@ -106,7 +106,7 @@ struct FrameSlot {
     void release()
     {
         DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_clips, &d_status, &d_lit, &d_valid, &d_quads, &d_sil, &d_counters,
-                           &d_bin_count, &d_bin_offset, &d_items, &d_work, &d_quad_work, &d_tile_stats,
+                           &d_bin_count, &d_bin_offset, &d_scan_part, &d_items, &d_work, &d_quad_work, &d_tile_stats,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
         if (events_ok) {
@@ -137,6 +137,7 @@ struct mr_scene {
     // ---- device copies of the static scene
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
     DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
+    DevBuf d_gamma;                          // GAMMA_LUT_SIZE float32 thresholds of the finalise step function
     int32_t sky_size = 0;
 
     // ---- frame slots, one per stream that has rendered this scene
@@ -195,10 +196,39 @@ void build_edge_table(mr_scene *sc)
     sc->edge_offset.push_back((uint32_t)keys.size());
 }
 
+// Finalise is uint8(frame ** 0.8 * 255) in float32 (obj/core.py:640): a monotone step function
+// of the colour with 255 steps.  GAMMA_LUT[k] is the smallest float32 in [0, 1] whose step is
+// >= k, found by bisection over the bit patterns against the host's own powf, so that k_shade
+// can place a colour with one approximate exp2/log2 and two table compares and still return
+// exactly what powf would (k_shade's gamma_u8).
+std::vector<float> gamma_thresholds()
+{
+    auto step = [](float x) { return (int)(uint8_t)(powf(x, 0.8f) * 255.0f); };
+    std::vector<float> lut(mr::GAMMA_LUT_SIZE);
+    lut[0] = 0.0f;
+    for (int k = 1; k < 256; ++k) {
+        uint32_t lo = 0, hi = 0x3f800000u;      // step(0) = 0 < k <= 255 = step(1)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            float x;
+            memcpy(&x, &mid, 4);
+            if (step(x) >= k) hi = mid; else lo = mid;
+        }
+        memcpy(&lut[k], &hi, 4);
+    }
+    lut[256] = INFINITY;
+    return lut;
+}
+
 int commit(mr_scene *sc)
 {
     if (!sc->dirty) return MR_OK;
     HIP_TRY(hipDeviceSynchronize());          // no frame may still be reading the old arrays
+    if (!sc->d_gamma.p) {
+        const std::vector<float> lut = gamma_thresholds();
+        HIP_TRY(sc->d_gamma.ensure(lut.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(sc->d_gamma.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     build_edge_table(sc);
     int rc;
     if ((rc = upload(sc->d_verts, sc->verts, g_stream))) return rc;
@@ -309,6 +339,13 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     HIP_TRY(fs->d_counters.ensure(sizeof(Counters)));
     HIP_TRY(fs->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
     HIP_TRY(fs->d_bin_offset.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
+    const int scan_blocks = blocks_for(BIN_CLASSES * n_tiles, SCAN_ITEMS) > 0 ? blocks_for(BIN_CLASSES * n_tiles, SCAN_ITEMS) : 1;
+    {
+        const void *had = fs->d_scan_part.p;
+        HIP_TRY(fs->d_scan_part.ensure((size_t)scan_blocks * 8));
+        if (fs->d_scan_part.p != had)       // epoch tags start below every frame's epoch (>= 1)
+            HIP_TRY(hipMemsetAsync(fs->d_scan_part.p, 0, fs->d_scan_part.cap, stream));
+    }
     HIP_TRY(fs->d_items.ensure((size_t)fs->item_cap * 4));
     HIP_TRY(fs->d_work.ensure((size_t)fs->work_cap * sizeof(uint2)));
     HIP_TRY(fs->d_quad_work.ensure((size_t)fs->quad_work_cap * sizeof(uint4)));
@@ -346,7 +383,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         hipLaunchKernelGGL(k_vertex_mfma, dim3(blocks_for(fc.n_vertices, 64)), dim3(256), 0, stream, fc,
                            sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr);
     if (fc.n_faces > 0)
-        hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
+        hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, SETUP_BLOCK)), dim3(SETUP_BLOCK), 0, stream, fc,
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
                            fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), fs->d_tris.as<TriRec>(),
                            fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), fs->d_lit.as<uint8_t>(),
@@ -387,8 +424,9 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
     hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[4], stream));
-    hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, stream, fs->d_bin_count.as<uint32_t>(),
-                       fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr);
+    hipLaunchKernelGGL(k_scan_bins, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, stream, fs->d_bin_count.as<uint32_t>(),
+                       fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr,
+                       fs->d_scan_part.as<unsigned long long>(), (uint32_t)(fs->frames_enqueued % 0xfffffffeull) + 1u);
     hipLaunchKernelGGL(k_bin_fill, dim3(classify_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
                        classify_blocks, large_blocks);
     HIP_TRY(hipEventRecord(fs->ev[5], stream));
@@ -419,6 +457,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.winner = fs->d_winner.as<int32_t>(); sa.stencil = fs->d_stencil.as<int32_t>();
     sa.sky = sc->sky_size > 0 ? sc->d_sky.as<uint8_t>() : nullptr;
     sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
+    sa.gamma_lut = sc->d_gamma.as<float>();
     sa.out = d_out;
     hipLaunchKernelGGL(k_shade, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc, sa);
     HIP_TRY(hipEventRecord(fs->ev[8], stream));
@@ -458,7 +497,7 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
     s.stencil_updates = (int64_t)c.stencil_updates;
     s.n_faces = (int64_t)(sc->faces.size() / 12); s.n_faces_setup = c.n_valid_tris;
     s.n_quads = c.n_quads; s.n_quads_drawn = c.n_quads_drawn;
-    s.tri_bin_entries = c.tri_bin_total; s.quad_bin_entries = c.quad_bin_total;
+    s.tri_bin_entries = c.tri_bin_total; s.quad_bin_entries = c.bin_total - c.tri_bin_total;
     sc->n_silhouette = (int)c.n_quads;
     float ms = 0;
     auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, fs->ev[a], fs->ev[b]); return ms; };
@@ -469,7 +508,7 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
     s.gpu_ms_total = span(0, with_copy ? 9 : 8);
     bool grown = false;
     if (c.overflow) {
-        const uint32_t entries = c.tri_bin_total + c.quad_bin_total;
+        const uint32_t entries = c.bin_total;
         if (c.overflow & 1u) fs->item_cap = entries + entries / 2 + 1024;
         if (c.overflow & 2u) fs->work_cap = c.n_work + c.n_work / 2 + 1024;
         if (c.overflow & 4u) fs->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, fs->quad_cap * 2);
@@ -561,7 +600,7 @@ void mr_scene_destroy(mr_scene *sc)
     if (!sc) return;
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
-                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_sky };
+                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_sky, &sc->d_gamma };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();
     delete sc;

@@ -131,7 +131,7 @@ struct Counters {
     unsigned int n_valid_tris, n_quads, n_quads_drawn;
     unsigned int n_count;        // faces whose survivor count is left to k_tri_count
     unsigned int pad2;
-    unsigned int tri_bin_total, quad_bin_total;
+    unsigned int tri_bin_total, bin_total;     // items of the two triangle classes; of all three
     unsigned int n_work;         // (large primitive, 64-tile chunk) work items of the binning pass
     unsigned int n_quad_work;    // (tile, quad batch) work items of the stencil pass
     unsigned int overflow;       // bit0: bin items, bit1: binning work list, bit2: quad list, bit3: quad work list
