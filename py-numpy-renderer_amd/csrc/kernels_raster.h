@@ -94,13 +94,16 @@ constexpr int BIN_SMALL = 4;      // primitives touching <= this many tiles are 
 struct PrimBox { int x0, x1, y0, y1; };
 
 __device__ __forceinline__ bool prim_span(const FrameConst &fc, const BinArgs &a, uint32_t u, uint32_t n_tris,
-                                          uint32_t n_quads, bool &is_quad, uint32_t &id, PrimBox &pb, TileSpan &sp)
+                                          uint32_t n_quads, bool &is_quad, bool &clip, uint32_t &id, PrimBox &pb,
+                                          TileSpan &sp)
 {
+    clip = false;
     if (u < n_tris) {
         is_quad = false;
         id = a.valid_list[u];
         const TriRec &t = a.tris[id];
         pb = { t.x0, t.x1, t.y0, t.y1 };
+        clip = (t.flags & TF_CLIP) != 0;
         return a.status[id] == FACE_OK && tile_span(fc, pb.x0, pb.x1, pb.y0, pb.y1, sp);
     }
     if (u < n_tris + n_quads) {
@@ -113,10 +116,16 @@ __device__ __forceinline__ bool prim_span(const FrameConst &fc, const BinArgs &a
     return false;
 }
 
-// bin class of a (primitive, tile) pair
-__device__ __forceinline__ int pair_class(const FrameConst &fc, bool is_quad, const PrimBox &pb, int tx, int ty)
+// Bin class of a (primitive, tile) pair: 0 small triangle pair (walked by a few lanes), 1 big
+// triangle pair (one pixel per lane), 2 shadow quad.  A triangle whose fragments need the
+// per-fragment clip test always goes the per-pixel way: there its corner data is wavefront-
+// uniform (scalar loads), whereas lanes that each test their own triangle would need 36 more
+// vector registers for it, halving the workgroups a CU can hold for a path that only
+// triangles on the frustum's border take.
+__device__ __forceinline__ int pair_class(const FrameConst &fc, bool is_quad, bool clip, const PrimBox &pb, int tx, int ty)
 {
     if (is_quad) return 2;
+    if (clip) return 1;
     const int gx = tx * TILE_W, gy = (ty + fc.tile_y0) * TILE_H;
     const int w = min(pb.x1, gx + TILE_W) - max(pb.x0, gx);
     const int h = min(min(pb.y1, gy + TILE_H), fc.band_y1) - max(max(pb.y0, gy), fc.band_y0);
@@ -171,11 +180,11 @@ __device__ __forceinline__ void bin_classify_body(const FrameConst &fc, const Bi
     const uint32_t n_tris = a.ctr->n_valid_tris, n_quads = min(a.ctr->n_quads_drawn, a.quad_cap);
     const uint32_t u = block * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
-    bool is_quad = false;
+    bool is_quad = false, clip = false;
     uint32_t id = 0;
     TileSpan sp = { 0, 0, 0, 0 };
     PrimBox pb = { 0, 0, 0, 0 };
-    const bool valid = prim_span(fc, a, u, n_tris, n_quads, is_quad, id, pb, sp);
+    const bool valid = prim_span(fc, a, u, n_tris, n_quads, is_quad, clip, id, pb, sp);
     const int ntiles = valid ? (sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0) : 0;
     // small primitives: up to BIN_SMALL (tile) pairs per lane, emitted one "slot" at a time so
     // that the wavefront can combine lanes that hit the same bin
@@ -188,7 +197,7 @@ __device__ __forceinline__ void bin_classify_body(const FrameConst &fc, const Bi
             const int tx = sp.tx0 + slot % bw, ty = sp.ty0 + slot / bw;
             const bool want = has && (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0));
             if (!__ballot(has)) break;
-            bin_emit_wave<FILL>(fc, a, want, want ? pair_class(fc, is_quad, pb, tx, ty) : 0, id, tx, ty);
+            bin_emit_wave<FILL>(fc, a, want, want ? pair_class(fc, is_quad, clip, pb, tx, ty) : 0, id, tx, ty);
         }
     }
     if (FILL) {
@@ -240,17 +249,17 @@ __device__ __forceinline__ void bin_large_body(const FrameConst &fc, const BinAr
     const uint32_t waves = n_blocks * (blockDim.x / WAVE);
     for (uint32_t w = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; w < n_work; w += waves) {
         const uint2 item = a.work[w];
-        bool is_quad;
+        bool is_quad, clip;
         uint32_t id;
         TileSpan sp;
         PrimBox pb;
-        if (!prim_span(fc, a, item.x, n_tris, n_quads, is_quad, id, pb, sp)) continue;
+        if (!prim_span(fc, a, item.x, n_tris, n_quads, is_quad, clip, id, pb, sp)) continue;
         const int bw = sp.tx1 - sp.tx0, total = bw * (sp.ty1 - sp.ty0);
         const int j = (int)item.y * WAVE + lane;
         if (j >= total) continue;
         const int tx = sp.tx0 + j % bw, ty = sp.ty0 + j / bw;
         if (!is_quad || quad_touches_tile(a.quads[id], tx, ty + fc.tile_y0))
-            bin_emit<FILL>(fc, a, pair_class(fc, is_quad, pb, tx, ty), id, tx, ty);
+            bin_emit<FILL>(fc, a, pair_class(fc, is_quad, clip, pb, tx, ty), id, tx, ty);
     }
 }
 
@@ -380,40 +389,46 @@ __device__ __forceinline__ double z_unkey(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
-// One small (triangle, tile) pair walked by one thread: every sample of the pixel box that
-// lies in the tile.  SWEEP 0: atomicMin/Max of z into the tile's LDS z-buffer.  SWEEP 1: the
-// same samples again; where this face's z is the final z, atomicMax of the face index.
+// One small (triangle, tile) pair shared by SMALL_LANES neighbouring lanes: the samples of the
+// pixel box that lie in the tile are dealt to them round-robin (a tile of a dense mesh lists
+// 50-200 such pairs of 1-24 samples each; one lane per pair left three of the four wavefronts
+// idle behind long serial walks).  SWEEP 0: atomicMin/Max of z into the tile's LDS z-buffer.
+// SWEEP 1: the same samples again; where this face's z is the final z, atomicMax of the face
+// index.  Pairs that need the per-fragment clip test never come here (pair_class).
+constexpr int SMALL_LANES = 4;
+
 template <int SWEEP>
 __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, const TriClip *clips,
                                            int gx, int gy, bool rh, unsigned long long *s_key, int *s_win,
-                                           unsigned int &frags)
+                                           int sub, unsigned int &frags)
 {
     const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
     const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
     const bool single = (t.flags & TF_SINGLE_BOX) != 0;
-    for (int py = y0; py < y1; ++py) {
-        for (int px = x0; px < x1; ++px) {
-            float u, v, w;
-            tri_bary(t, (double)px, (double)py, single, u, v, w);
-            if (!(u >= 0 && v >= 0 && w >= 0)) continue;
-            if (SWEEP == 0) ++frags;
-            if (t.flags & TF_CLIP) {
-                const TriClip &c = clips[t.face];
-                double p[3];
-                persp_bary(c.dp, u, v, w, single, p);
-                if (!(inside_clip(p, c.clip) && inside_clip(p, c.clipd))) continue;
-            }
+    const int bw = x1 - x0;
+    if (bw <= 0) return;
+    int px = x0 + sub, py = y0;
+    while (px >= x1) { px -= bw; ++py; }
+    while (py < y1) {
+        float u, v, w;
+        tri_bary(t, (double)px, (double)py, single, u, v, w);
+        bool ok = u >= 0 && v >= 0 && w >= 0;
+        if (ok && SWEEP == 0) ++frags;
+        if (ok) {
             const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
                                        t.zl0, t.zl1, t.zl2);
-            if (z != z) continue;                    // a NaN depth never passes the reference's test
-            const int p = (py - gy) * TILE_W + (px - gx);
-            const unsigned long long k = z_key(z);
-            if (SWEEP == 0) {
-                if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
-            } else if (s_key[p] == k) {
-                atomicMax(&s_win[p], t.face);
+            if (z == z) {                            // a NaN depth never passes the reference's test
+                const int p = (py - gy) * TILE_W + (px - gx);
+                const unsigned long long k = z_key(z);
+                if (SWEEP == 0) {
+                    if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
+                } else if (s_key[p] == k) {
+                    atomicMax(&s_win[p], t.face);
+                }
             }
         }
+        px += SMALL_LANES;
+        while (px >= x1) { px -= bw; ++py; }
     }
 }
 
@@ -492,29 +507,32 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
             if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
         }
     }
+    const unsigned long long t_big = __builtin_amdgcn_s_memrealtime();
     __syncthreads();                                      // s_cnt is zeroed
     if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
     s_key[lp] = z_key(zbest);
     __syncthreads();
 
-    // ---- small pairs, one triangle per thread, z into the LDS z-buffer
+    // ---- small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
     unsigned int sfrags = 0;
-    for (uint32_t i = sbeg + tid; i < send; i += TILE_PX) {
+    for (uint32_t i = sbeg + tid / SMALL_LANES; i < send; i += TILE_PX / SMALL_LANES) {
         const TriRec t = tris[items[i]];
-        small_pair<0>(fc, t, clips, gx, gy, rh, s_key, s_win, sfrags);
+        small_pair<0>(fc, t, clips, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
     }
     if (sfrags) atomicAdd(&s_cnt[0], sfrags);
     __syncthreads();
+    const unsigned long long t_sweep0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- winners: big pairs keep their face where their z survived, then the small pairs' sweep
     const unsigned long long kfinal = s_key[lp];
     s_win[lp] = (best >= 0 && kfinal == z_key(zbest)) ? best : -1;
     __syncthreads();
-    for (uint32_t i = sbeg + tid; i < send; i += TILE_PX) {
+    for (uint32_t i = sbeg + tid / SMALL_LANES; i < send; i += TILE_PX / SMALL_LANES) {
         const TriRec t = tris[items[i]];
-        small_pair<1>(fc, t, clips, gx, gy, rh, s_key, s_win, sfrags);
+        small_pair<1>(fc, t, clips, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
     }
     __syncthreads();
+    const unsigned long long t_sweep1 = __builtin_amdgcn_s_memrealtime();
     best = s_win[lp];
     zbest = z_unkey(kfinal);
 
@@ -532,8 +550,19 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
     if (tid < TILE_STATS) tile_stats[(size_t)tile * TILE_REC + tid] = s_cnt[tid];
     if (tid == 0) {                                       // diagnostics for mr_debug_read_tile_records
         uint32_t *o = tile_stats + (size_t)tile * TILE_REC;
+#if defined(TILE_PHASE) && TILE_PHASE == 1
+        o[5] = (uint32_t)t_start; o[6] = (uint32_t)t_big;
+#elif defined(TILE_PHASE) && TILE_PHASE == 2
+        o[5] = (uint32_t)t_big; o[6] = (uint32_t)t_sweep0;
+#elif defined(TILE_PHASE) && TILE_PHASE == 3
+        o[5] = (uint32_t)t_sweep0; o[6] = (uint32_t)t_sweep1;
+#elif defined(TILE_PHASE) && TILE_PHASE == 4
+        o[5] = (uint32_t)t_sweep1; o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#else
+        (void)t_big; (void)t_sweep0; (void)t_sweep1;
         o[5] = (uint32_t)t_start;
         o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         o[7] = min(send - sbeg, 0xfffu) | (min(bend - bbeg, 0x3ffu) << 12) | (min(qend - qbeg, 0x3ffu) << 22);
     }
     if (tid < BIN_CLASSES) bin_count[tid * n_tiles + tile] = 0;   // bin cursors zeroed for the next frame

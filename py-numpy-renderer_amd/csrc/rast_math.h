@@ -9,6 +9,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/mi355rast.h"
+#include "rast_types.h"
+
 namespace mr {
 
 // 1-D dot and GEMM (M,K)@(K,P>=2): ascending k, first term a rounded product.
@@ -90,14 +93,40 @@ __device__ __forceinline__ void tri_bary(const TriRec &t, double dpx, double dpy
     u = 1.0f - v - w;
 }
 
+// a0/b, a1/b, a2/b with ONE reciprocal, bit-identical to IEEE-754 division.  The compiler's
+// division is v_div_scale x2, v_rcp_f64, two Newton steps, a residual correction (v_div_fmas)
+// and v_div_fixup, ~30 instructions each; the scale and fix-up steps only act on operands near
+// the ends of the exponent range or on specials, and the reciprocal and its refinement depend
+// on the denominator alone.  With every exponent well inside the range this shares them and
+// keeps only the quotient + residual step per numerator (14 instructions instead of 90 for the
+// three); anything else (zero denominators, denormals, infinities, NaN, huge ratios) takes the
+// compiler's division.  Returns whether the shared path was taken.  Checked against "/" on
+// MI355X over 1e9 operand sets, 0 mismatches (tools/micro/div_check.hip).
+__device__ __forceinline__ bool div3(double a0, double a1, double a2, double b, double q[3])
+{
+    auto expo = [](double x) { return (unsigned int)(__double2hiint(x) >> 20) & 0x7ffu; };
+    auto mid = [&](double x) { const unsigned int e = expo(x); return e > 0x200u && e < 0x5ffu; };
+    const bool fast = mid(b) && (mid(a0) || a0 == 0) && (mid(a1) || a1 == 0) && (mid(a2) || a2 == 0);
+    if (fast) {
+        double r = __builtin_amdgcn_rcp(b);
+        r = fma(fma(-b, r, 1.0), r, r);
+        r = fma(fma(-b, r, 1.0), r, r);
+        const double t0 = a0 * r, t1 = a1 * r, t2 = a2 * r;
+        q[0] = fma(fma(-b, t0, a0), r, t0);
+        q[1] = fma(fma(-b, t1, a1), r, t1);
+        q[2] = fma(fma(-b, t2, a2), r, t2);
+    } else {
+        q[0] = a0 / b; q[1] = a1 / b; q[2] = a2 / b;
+    }
+    return fast;
+}
+
 // Face.screen_perspective (obj/core.py:155-160)
 __device__ __forceinline__ void persp_bary(const double dp[3], float u, float v, float w, bool single,
                                            double p[3])
 {
     double wc = rows_dot3(single, (double)u, (double)v, (double)w, dp[0], dp[1], dp[2]);
-    p[0] = ((double)u * dp[0]) / wc;
-    p[1] = ((double)v * dp[1]) / wc;
-    p[2] = ((double)w * dp[2]) / wc;
+    div3((double)u * dp[0], (double)v * dp[1], (double)w * dp[2], wc, p);
 }
 
 // strict -w < x,y,z < w in one camera's clip space (obj/triangular.py:83-87)
