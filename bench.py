@@ -118,6 +118,12 @@ def main():
                       frames_in_flight=args.frames_in_flight)
     rows = br.band[1] - br.band[0]
     step = br.step
+    # The counters of this rank's band, from one counted frame (MR_FRAME_COUNTERS).  The timed
+    # frames are rendered the way Scene.render() renders them, without the counters: like the
+    # reference, which counts nothing, they produce the frame only; it is checked below against
+    # a counted single-device frame.
+    backend.render(scene, shadows=True, row_band=br.band)
+    band_stats = dict(backend.last_stats)
 
     for _ in range(args.warmup):
         step()
@@ -139,7 +145,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    band_stats = backend.stats()
+    backend.stats()                      # raises if a work list overflowed in the timed frames
     ktimes, n_avg = backend.kernel_times(min(args.steps, 128))
 
     if rank == 0:

@@ -48,7 +48,12 @@ enum {
     MR_FRAME_KEEP_FLOAT = 2,  /* also keep the float32 frame (needed by mr_read_frame_f32) */
     MR_FRAME_FACE_STATUS = 4, /* also compute the per-face status histogram (obj/core.py:625-636) */
     MR_FRAME_LIGHT_TIMING = 8, /* record only the event marks around the frame and the visibility kernels */
-    MR_FRAME_SKYBOX = 16      /* fill the background from the cubemap of mr_scene_set_skybox (obj/core.py:595-596) */
+    MR_FRAME_SKYBOX = 16,     /* fill the background from the cubemap of mr_scene_set_skybox (obj/core.py:595-596) */
+    MR_FRAME_COUNTERS = 32    /* keep the reference-equivalent fragment counters of mr_stats, and the reference's
+                                 stencil values at pixels no triangle covers (mr_read_stencil).  Without it only
+                                 the frame is the contract and the library skips work that cannot change it
+                                 (shadow quads that cannot pass the depth test anywhere in a strip of pixels);
+                                 mr_render sets it by itself when it is handed a stats pointer. */
 };
 
 typedef struct mr_scene mr_scene;

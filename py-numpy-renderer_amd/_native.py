@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 
 MR_OK = 0
 MR_E_OVERFLOW = -4
-FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SKYBOX = 1, 2, 4, 8, 16
+FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SKYBOX, FRAME_COUNTERS = 1, 2, 4, 8, 16, 32
 
 
 class FrameDesc(C.Structure):
@@ -116,12 +116,13 @@ def _check(rc, what):
     return rc
 
 
-def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False):
+def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False, counters=False):
     d = FrameDesc()
     d.width, d.height, d.system = pf.width, pf.height, pf.system
     d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
     d.flags = ((FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
-               | (FRAME_LIGHT_TIMING if light_timing else 0) | (FRAME_FACE_STATUS if face_status else 0))
+               | (FRAME_LIGHT_TIMING if light_timing else 0) | (FRAME_FACE_STATUS if face_status else 0)
+               | (FRAME_COUNTERS if counters else 0))
     d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
     for name in ("mvp", "viewport", "debug_mvp", "frustum_planes", "camera_pos", "light_pos", "light_dir",
                  "light_color", "light_ambient"):
@@ -212,27 +213,37 @@ class DeviceRenderer:
         self._sky_key = key
 
     # -- frames ---------------------------------------------------------------------------
-    def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False):
-        """``mr_render``: returns the uint8 band ``(rows, W, 3)`` as a NumPy array."""
+    def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False, counters=True):
+        """``mr_render``: returns the uint8 band ``(rows, W, 3)`` as a NumPy array.
+
+        ``counters=True`` (``MR_FRAME_COUNTERS``) also keeps the reference-equivalent fragment
+        counters in ``last_stats`` and the reference's stencil values at uncovered pixels --
+        what the parity tests and tools look at.  ``Scene.render`` passes ``False``: only the
+        frame is asked for, and shadow quads that cannot pass the depth test are skipped
+        (``last_stats`` then reports the fragment counters as -1)."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status)
+        desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status, counters=counters)
         self._n_faces = sum(len(m._faces) for m in scene.models)
         rows = desc.row_end - desc.row_begin
         out = np.empty((rows, pf.width, 3), dtype=np.uint8)
         stats = Stats()
-        _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats)), "mr_render")
+        _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats) if counters else None),
+               "mr_render")
+        if not counters:
+            _check(self.lib.mr_get_stats(self.handle, C.byref(stats)), "mr_get_stats")
         self.last_stats = stats.as_dict()
         self._frame = (pf.height, pf.width)
         return out
 
-    def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False):
+    def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False,
+                      counters=False):
         """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, False, light_timing)
+        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
         self._frame = (pf.height, pf.width)

@@ -352,7 +352,8 @@ class Scene:
         backend = self._backend()
         report = self.verbose and row_band is None
         overlay = self.draw_debug_frustum and row_band is None
-        out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, keep_float=overlay)
+        out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, keep_float=overlay,
+                             counters=False)
         self.last_stats = backend.last_stats
         if report:
             self._print_face_report(backend.read_face_status())

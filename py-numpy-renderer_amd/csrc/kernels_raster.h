@@ -507,7 +507,6 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
             if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
         }
     }
-    const unsigned long long t_big = __builtin_amdgcn_s_memrealtime();
     __syncthreads();                                      // s_cnt is zeroed
     if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
     s_key[lp] = z_key(zbest);
@@ -521,7 +520,6 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
     }
     if (sfrags) atomicAdd(&s_cnt[0], sfrags);
     __syncthreads();
-    const unsigned long long t_sweep0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- winners: big pairs keep their face where their z survived, then the small pairs' sweep
     const unsigned long long kfinal = s_key[lp];
@@ -532,7 +530,6 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
         small_pair<1>(fc, t, clips, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
     }
     __syncthreads();
-    const unsigned long long t_sweep1 = __builtin_amdgcn_s_memrealtime();
     best = s_win[lp];
     zbest = z_unkey(kfinal);
 
@@ -550,85 +547,129 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
     if (tid < TILE_STATS) tile_stats[(size_t)tile * TILE_REC + tid] = s_cnt[tid];
     if (tid == 0) {                                       // diagnostics for mr_debug_read_tile_records
         uint32_t *o = tile_stats + (size_t)tile * TILE_REC;
-#if defined(TILE_PHASE) && TILE_PHASE == 1
-        o[5] = (uint32_t)t_start; o[6] = (uint32_t)t_big;
-#elif defined(TILE_PHASE) && TILE_PHASE == 2
-        o[5] = (uint32_t)t_big; o[6] = (uint32_t)t_sweep0;
-#elif defined(TILE_PHASE) && TILE_PHASE == 3
-        o[5] = (uint32_t)t_sweep0; o[6] = (uint32_t)t_sweep1;
-#elif defined(TILE_PHASE) && TILE_PHASE == 4
-        o[5] = (uint32_t)t_sweep1; o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#else
-        (void)t_big; (void)t_sweep0; (void)t_sweep1;
         o[5] = (uint32_t)t_start;
         o[6] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
         o[7] = min(send - sbeg, 0xfffu) | (min(bend - bbeg, 0x3ffu) << 12) | (min(qend - qbeg, 0x3ffu) << 22);
     }
     if (tid < BIN_CLASSES) bin_count[tid * n_tiles + tile] = 0;   // bin cursors zeroed for the next frame
 }
 
 // Shadow quads against the final z: stencil +-1 (obj/triangular.py:335-368).  One workgroup
-// per work item (tile, <= QUAD_BATCH quads), one pixel per thread; the item's records are
-// staged in registers and broadcast.  The stencil lives in a 32-bit buffer that k_tile_raster
-// zeroed; items of one tile add into it with coalesced atomics (adds commute, so the order of
-// the quads never mattered: obj/triangular.py:365-368).
+// per work item (tile, <= QUAD_BATCH quads), one pixel per thread.  The item's records (header
+// and first four edges: 192 bytes each) are copied to LDS once, 16 bytes per lane, and every
+// lane then reads the quad it is testing at the same LDS address (a broadcast read): fetching
+// them per wavefront and handing them round with v_readlane cost ~45 readlanes, with their
+// SGPR hazards, per quad and wavefront.  The stencil lives in a 32-bit buffer that
+// k_tile_raster zeroed; items of one tile add into it with coalesced atomics (adds commute, so
+// the order of the quads never mattered: obj/triangular.py:365-368).
+constexpr int QUAD_STAGE_U4 = 12;     // uint4 pieces staged per quad: 64-byte header + 4 edges
+static_assert(offsetof(QuadRec, e) == 64 && sizeof(QuadEdge) == 32, "QuadRec layout");
+
+struct QuadHead {                     // the first 64 bytes of a QuadRec, as staged
+    double nx, ny, nz, d;
+    int16_t x0, x1, y0, y1;
+    int32_t n, is_front, edge;
+    uint32_t pad[3];
+};
+static_assert(sizeof(QuadHead) == 64, "QuadHead mirrors QuadRec's header");
+
 __global__ void __launch_bounds__(TILE_PX)
 k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4 *__restrict__ quad_work,
              uint32_t quad_work_cap, const uint32_t *__restrict__ items, uint32_t item_cap,
-             const double *__restrict__ zbuf, int32_t *__restrict__ stencil, uint32_t *__restrict__ tile_stats,
-             const Counters *__restrict__ ctr)
+             const double *__restrict__ zbuf, const int32_t *__restrict__ winner, int32_t *__restrict__ stencil,
+             uint32_t *__restrict__ tile_stats, const Counters *__restrict__ ctr)
 {
+    __shared__ uint4 s_quad[QUAD_BATCH * QUAD_STAGE_U4];
+    __shared__ uint32_t s_id[QUAD_BATCH];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const uint32_t n_work = min(ctr->n_quad_work, quad_work_cap);
     const bool rh = fc.system == 1;
+    const bool counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
     for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const uint4 item = quad_work[wi];
         const int tile = (int)item.x;
         const uint32_t base = item.y;
-        const int n = (int)min(item.z, item_cap > base ? item_cap - base : 0u);
+        const int n = (int)min(min(item.z, (uint32_t)QUAD_BATCH), item_cap > base ? item_cap - base : 0u);
         const int gx = (tile % fc.tiles_x) * TILE_W, gy = (tile / fc.tiles_x + fc.tile_y0) * TILE_H;
         const int px = gx + (tid & (TILE_W - 1)), py = gy + tid / TILE_W;
         const bool live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
         const double dpx = (double)px, dpy = (double)py;
         const size_t at = (size_t)py * fc.width + px;
         const double zbest = live ? zbuf[at] : 0.0;
-
-        const uint32_t myid = n > 0 ? items[base + min(lane, n - 1)] : 0u;
-        const QuadRec *mq = quads + myid;
-        const double m_nx = mq->nx, m_ny = mq->ny, m_nz = mq->nz, m_d = mq->d;
-        const int m_bx = (int)(uint16_t)mq->x0 | ((int)(uint16_t)mq->x1 << 16);
-        const int m_by = (int)(uint16_t)mq->y0 | ((int)(uint16_t)mq->y1 << 16);
-        const int m_nf = mq->n | (mq->is_front ? 0x100 : 0);
-        QuadEdge me[4];
+        // most favourable covered z of this wavefront's strip (see the depth cull below)
+        double zlim = rh ? -INFINITY : INFINITY;
+        if (!counters) {
+            if (live && winner[at] >= 0) zlim = zbest;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) me[i] = mq->e[i];
+            for (int off = WAVE / 2; off; off >>= 1) {
+                const double o = __shfl_xor(zlim, off);
+                zlim = rh ? fmax(zlim, o) : fmin(zlim, o);
+            }
+        }
 
-        // Lane j classifies ITS quad against this wavefront's 16x4 pixel strip with the same
+        if (tid < n * QUAD_STAGE_U4) {
+            const int q = tid / QUAD_STAGE_U4, piece = tid - q * QUAD_STAGE_U4;
+            const uint32_t id = items[base + q];
+            s_quad[tid] = reinterpret_cast<const uint4 *>(quads + id)[piece];
+            if (piece == 0) s_id[q] = id;
+        }
+        __syncthreads();
+
+        // Lane j classifies quad j against this wavefront's 16x4 pixel strip with the same
         // corner argument as quad_touches_tile: per edge, the rounded cross product is monotone
         // in x and in y, so over the strip it is extreme at a corner.  No corner on the inner
-        // side of some edge -> no sample of the strip is inside (skip the quad: most of a
-        // tile's quads miss most of its strips); all four corners on the inner side of every
-        // edge -> every sample is inside (skip the per-pixel edge tests).  Exact, no margins.
-        bool q_reject = lane >= n, q_accept = !q_reject && (m_nf & 0xff) <= 4;
-        {
+        // side of some edge -> no sample of the strip is inside (skip the quad); all four
+        // corners on the inner side of every edge -> every sample is inside (skip the
+        // per-pixel edge tests).  Exact, no margins.
+        bool q_reject = lane >= n, q_accept = false;
+        if (!q_reject) {
+            const QuadHead &h = *reinterpret_cast<const QuadHead *>(s_quad + lane * QUAD_STAGE_U4);
+            const QuadEdge *e = reinterpret_cast<const QuadEdge *>(s_quad + lane * QUAD_STAGE_U4 + 4);
             const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
             const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
-            const bool m_front = (m_nf & 0x100) != 0;
+            const bool front = h.is_front != 0;
+            q_accept = h.n <= 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i < 3 || (m_nf & 0xff) > 3) {
-                    const double px0 = (xa - me[i].sx) * me[i].ey, px1 = (xb - me[i].sx) * me[i].ey;
-                    const double py0 = (ya - me[i].sy) * me[i].ex, py1 = (yb - me[i].sy) * me[i].ex;
+                if (i < 3 || h.n > 3) {
+                    const double px0 = (xa - e[i].sx) * e[i].ey, px1 = (xb - e[i].sx) * e[i].ey;
+                    const double py0 = (ya - e[i].sy) * e[i].ex, py1 = (yb - e[i].sy) * e[i].ex;
                     const double c00 = px0 - py0, c10 = px1 - py0, c01 = px0 - py1, c11 = px1 - py1;
-                    const bool any = m_front ? (c00 > 0 || c10 > 0 || c01 > 0 || c11 > 0)
-                                             : (c00 < 0 || c10 < 0 || c01 < 0 || c11 < 0);
-                    const bool all = m_front ? (c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0)
-                                             : (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0);
+                    const bool any = front ? (c00 > 0 || c10 > 0 || c01 > 0 || c11 > 0)
+                                           : (c00 < 0 || c10 < 0 || c01 < 0 || c11 < 0);
+                    const bool all = front ? (c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0)
+                                           : (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0);
                     q_reject = q_reject || !any;
                     q_accept = q_accept && all;
                 }
             }
+        }
+        if (!counters && !q_reject) {
+            // Depth cull, only when the frame is all that is asked for (no MR_FRAME_COUNTERS):
+            // the stencil matters where a triangle was drawn, and a quad changes it only where
+            // its depth passes against the z-buffer.  The quad's plane depth is affine over the
+            // screen, so over the strip -t/nz is extreme at a corner, and linearize_z is
+            // monotone while its denominator stays positive: if even the most favourable depth
+            // of the quad over the strip (pushed further by a slack that dwarfs the rounding of
+            // the per-pixel expression) loses against the most favourable covered z of the
+            // strip, no pixel of the strip can pass.  Nine in ten quad fragments fail the
+            // depth test in a typical frame.
+            const QuadHead &h = *reinterpret_cast<const QuadHead *>(s_quad + lane * QUAD_STAGE_U4);
+            const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
+            const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
+            const double t00 = (h.nx * xa + h.ny * ya) + h.d, t10 = (h.nx * xb + h.ny * ya) + h.d;
+            const double t01 = (h.nx * xa + h.ny * yb) + h.d, t11 = (h.nx * xb + h.ny * yb) + h.d;
+            const double tmin = fmin(fmin(t00, t10), fmin(t01, t11)), tmax = fmax(fmax(t00, t10), fmax(t01, t11));
+            const double inz = 1.0 / h.nz;
+            const double za = -tmin * inz, zb = -tmax * inz;
+            const double slack = 1e-12 * fmax(fabs(za), fabs(zb)) +
+                                 1e-15 * ((fabs(h.nx) * xb + fabs(h.ny) * yb) + fabs(h.d)) * fabs(inz);
+            const double zs_lo = fmin(za, zb) - slack, zs_hi = fmax(za, zb) + slack;
+            const double den_lo = fc.f_plus_n - zs_hi * fc.f_minus_n, den_hi = fc.f_plus_n - zs_lo * fc.f_minus_n;
+            // den_lo <= den <= den_hi over the strip; for 0 < den the depth two_nf / den falls as den grows
+            const bool sane = fc.two_nf > 0 && fc.f_minus_n > 0 && den_lo > 1e-9 * fc.f_plus_n;
+            const double zq_lo = fc.two_nf / den_hi * (1.0 - 1e-12), zq_hi = fc.two_nf / den_lo * (1.0 + 1e-12);
+            if (sane && (rh ? zq_lo > zlim : zq_hi < zlim)) q_reject = true;
         }
         unsigned long long todo = __ballot(!q_reject);
         const unsigned long long accepted = __ballot(q_accept);
@@ -638,25 +679,33 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
         while (todo) {
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const int bx = bcast(m_bx, j), by = bcast(m_by, j), nf = bcast(m_nf, j);
-            const bool front = (nf & 0x100) != 0;
-            const int nv = nf & 0xff;
-            bool in = live && px >= (bx & 0xffff) && px < (bx >> 16) && py >= (by & 0xffff) && py < (by >> 16);
+            // the whole record is fetched up front with plain 16-byte broadcast reads and the
+            // tests below are combined without short-circuits: written with && the compiler
+            // kept one LDS load per condition, each behind its own branch and wait
+            const uint4 *rec = s_quad + j * QUAD_STAGE_U4;
+            const uint4 hb = rec[2];
+            const uint4 ea0 = rec[4], eb0 = rec[5], ea1 = rec[6], eb1 = rec[7], ea2 = rec[8], eb2 = rec[9],
+                        ea3 = rec[10], eb3 = rec[11];
+            const int x0 = (int)(int16_t)(hb.x & 0xffffu), x1 = (int)(int16_t)(hb.x >> 16);
+            const int y0 = (int)(int16_t)(hb.y & 0xffffu), y1 = (int)(int16_t)(hb.y >> 16);
+            const int nv = (int)hb.z;
+            const bool front = hb.w != 0;
+            bool in = live & (px >= x0) & (px < x1) & (py >= y0) & (py < y1);
             if (!((accepted >> j) & 1)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < 3 || nv > 3) {
-                        const double ax = dpx - bcast(me[i].sx, j), ay = dpy - bcast(me[i].sy, j);
-                        const double cr = ax * bcast(me[i].ey, j) - ay * bcast(me[i].ex, j);
-                        in = in && (front ? cr > 0 : cr < 0);
-                    }
-                }
+                auto d2 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
+                auto inner = [&](const uint4 &a, const uint4 &b) {
+                    const double ax = dpx - d2(a.x, a.y), ay = dpy - d2(a.z, a.w);
+                    const double cr = ax * d2(b.z, b.w) - ay * d2(b.x, b.y);
+                    return front ? cr > 0 : cr < 0;
+                };
+                const bool i0 = inner(ea0, eb0), i1 = inner(ea1, eb1), i2 = inner(ea2, eb2), i3 = inner(ea3, eb3);
+                in = in & i0 & i1 & i2 & (i3 | (nv <= 3));
                 if (nv > 4) {                           // clipped polygons with 5+ vertices are rare
-                    const QuadRec *q = quads + bcast((int)myid, j);
+                    const QuadRec *q = quads + s_id[j];
                     for (int i = 4; i < nv; ++i) {
                         const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
                         const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
-                        in = in && (front ? cr > 0 : cr < 0);
+                        in = in & (front ? cr > 0 : cr < 0);
                     }
                 }
             }
@@ -668,8 +717,10 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
             // DECISION almost never does: an approximation good to 2e-10 (Newton-refined
             // v_rcp_f64) settles it unless z-buffer and quad depth agree to nine digits, and
             // only then is the exactly rounded expression evaluated.  Decisions stay bit-exact.
-            const double t = (bcast(m_nx, j) * dpx + bcast(m_ny, j) * dpy) + bcast(m_d, j);
-            const double nzq = bcast(m_nz, j);
+            const uint4 p0 = rec[0], p1 = rec[1];
+            const double q_nx = __hiloint2double((int)p0.y, (int)p0.x), q_ny = __hiloint2double((int)p0.w, (int)p0.z);
+            const double nzq = __hiloint2double((int)p1.y, (int)p1.x), q_d = __hiloint2double((int)p1.w, (int)p1.z);
+            const double t = (q_nx * dpx + q_ny * dpy) + q_d;
             const double zs_a = -t * approx_rcp(nzq);
             const double m_a = zs_a * fc.f_minus_n;
             const double den_a = fc.f_plus_n - m_a;
@@ -689,10 +740,11 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
             sten += pass ? (front ? 1 : -1) : 0;
         }
         if (sten) atomicAdd(&stencil[at], sten);
-        if (lane == 0) {
+        if (counters && lane == 0) {
             if (qfrags) atomicAdd(&tile_stats[(size_t)tile * TILE_REC + 1], qfrags);
             if (qupd) atomicAdd(&tile_stats[(size_t)tile * TILE_REC + 2], qupd);
         }
+        __syncthreads();                                  // the next item overwrites the staged records
     }
 }
 

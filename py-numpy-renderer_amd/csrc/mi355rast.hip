@@ -438,10 +438,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                        fs->d_bin_count.as<uint32_t>(), fs->d_z.as<double>(), fs->d_winner.as<int32_t>(),
                        fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>());
     HIP_TRY(hipEventRecord(fs->ev[6], stream));
+    static const unsigned quad_grid = [] { const char *e = getenv("MR_QUAD_GRID"); return e ? (unsigned)atoi(e) : 4096u; }();
     if (shadows)
-        hipLaunchKernelGGL(k_tile_quads, dim3(2048), dim3(TILE_PX), 0, stream, fc, fs->d_quads.as<QuadRec>(),
+        hipLaunchKernelGGL(k_tile_quads, dim3(quad_grid), dim3(TILE_PX), 0, stream, fc, fs->d_quads.as<QuadRec>(),
                            fs->d_quad_work.as<uint4>(), fs->quad_work_cap, fs->d_items.as<uint32_t>(), fs->item_cap,
-                           fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>(), ctr);
+                           fs->d_z.as<double>(), fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(),
+                           fs->d_tile_stats.as<uint32_t>(), ctr);
     HIP_TRY(hipEventRecord(fs->ev[7], stream));
     if ((fc.flags & MR_FRAME_FACE_STATUS) && fc.n_faces > 0)
         hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
@@ -477,7 +479,7 @@ int fetch_counters(mr_scene *sc, FrameSlot *fs)
 {
     using namespace mr;
     Counters *ctr = fs->d_counters.as<Counters>();
-    if (!fs->stats_reduced) {
+    if (!fs->stats_reduced && (fs->last_frame.flags & MR_FRAME_COUNTERS)) {
         const FrameConst fc = make_const(sc, &fs->last_frame);
         hipLaunchKernelGGL(k_reduce_tile_stats, dim3(512), dim3(256), 0, fs->stream, fc, fs->d_tile_stats.as<uint32_t>(),
                            fs->last_n_tiles, fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(), ctr);
@@ -492,9 +494,13 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
 {
     const mr::Counters &c = *fs->h_counters;
     mr_stats &s = sc->stats;
-    s.frag_tri = (int64_t)c.frag_tri; s.frag_quad = (int64_t)c.frag_quad;
-    s.covered_px = (int64_t)c.covered_px; s.lit_px = (int64_t)c.lit_px;
-    s.stencil_updates = (int64_t)c.stencil_updates;
+    if (fs->last_frame.flags & MR_FRAME_COUNTERS) {
+        s.frag_tri = (int64_t)c.frag_tri; s.frag_quad = (int64_t)c.frag_quad;
+        s.covered_px = (int64_t)c.covered_px; s.lit_px = (int64_t)c.lit_px;
+        s.stencil_updates = (int64_t)c.stencil_updates;
+    } else {                                  // not counted: the frame was rendered without MR_FRAME_COUNTERS
+        s.frag_tri = s.frag_quad = s.covered_px = s.lit_px = s.stencil_updates = -1;
+    }
     s.n_faces = (int64_t)(sc->faces.size() / 12); s.n_faces_setup = c.n_valid_tris;
     s.n_quads = c.n_quads; s.n_quads_drawn = c.n_quads_drawn;
     s.tri_bin_entries = c.tri_bin_total; s.quad_bin_entries = c.bin_total - c.tri_bin_total;
@@ -708,6 +714,9 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     if ((rc = ensure_init())) return rc;
     FrameSlot *fs = slot_for(sc, g_stream);
     if (!fs) return fail(MR_E_DEVICE, "out of frame slots");
+    mr_frame_desc counted = *fr;
+    if (stats) counted.flags |= MR_FRAME_COUNTERS;         // whoever asks for the counters gets them
+    fr = &counted;
     const size_t band_bytes = (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
     for (int attempt = 0; attempt < 6; ++attempt) {
         HIP_TRY(fs->d_out.ensure(band_bytes));

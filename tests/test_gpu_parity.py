@@ -64,6 +64,34 @@ def test_small_scene_matches_oracle(api, oracle_mod, name):
     scene.close()
 
 
+FRAME_ONLY = SMALL + ["c3_diablo_floor_1080p", "c4_torus200k_1080p"]
+
+
+@pytest.mark.parametrize("name", FRAME_ONLY)
+def test_frame_only_mode_renders_the_same_frame(api, name):
+    """Without MR_FRAME_COUNTERS (how Scene.render() and bench.py render) the library skips
+    shadow quads that cannot pass the depth test anywhere in a strip of pixels.  The frame,
+    the z-buffer, the winners and -- at every pixel a triangle covers -- the stencil must be
+    exactly those of the counted frame; the counters are reported as "not counted" (-1)."""
+    scene = scenes.build(api, name)
+    shadows = name not in scenes.NO_SHADOW
+    backend = scene._backend()
+    exact = backend.render(scene, shadows=shadows, keep_float=True, counters=True)
+    z, winner, stencil, frame = backend.read_z(), backend.read_winner(), backend.read_stencil(), backend.read_frame_f32()
+    assert backend.last_stats["frag_tri"] > 0
+    fast = backend.render(scene, shadows=shadows, keep_float=True, counters=False)
+    assert np.array_equal(fast, exact)
+    assert np.array_equal(backend.read_z().view(np.uint64), z.view(np.uint64))
+    assert np.array_equal(backend.read_winner(), winner)
+    assert np.array_equal(backend.read_frame_f32().view(np.uint32), frame.view(np.uint32))
+    covered = winner >= 0
+    assert np.array_equal(backend.read_stencil()[covered], stencil[covered])
+    assert backend.last_stats["frag_tri"] == -1 and backend.last_stats["frag_quad"] == -1
+    assert backend.last_stats["n_quads"] >= 0
+    assert np.array_equal(scene.render(shadows=shadows), exact)
+    scene.close()
+
+
 def test_render_is_repeatable_and_matches_scene_render(api):
     """Scene.render() (the drop-in call) returns the same frame on every call -- unlike the
     reference, whose silhouette set toggles between calls (obj/core.py:251,605)."""
