@@ -4,7 +4,7 @@ tag=$1; filt=$2; shift 2
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 > $out.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 frame-only > $out.log 2>&1
 python3 - "$out" "$filt" <<'PY'
 import csv, glob, sys, collections
 f = sorted(glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"))[-1]

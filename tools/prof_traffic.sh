@@ -3,8 +3,8 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc/traffic
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 > $out/fetch.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 > $out/write.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 frame-only > $out/fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $GRAFT_REPO_ROOT/tools/render_loop.py c4_torus200k_1080p 6 frame-only > $out/write.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys, json, collections
 res = collections.defaultdict(dict)

@@ -1,4 +1,5 @@
-"""Render a scene N times through mr_render (for rocprofv3 runs)."""
+"""Render a scene N times through mr_render (for rocprofv3 runs); a third argument "frame-only"
+renders the way Scene.render() and bench.py do (no MR_FRAME_COUNTERS)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -8,6 +9,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 api = scenes.product_api()
 sc = scenes.build(api, name)
 be = sc._backend()
+counters = not (len(sys.argv) > 3 and sys.argv[3] == "frame-only")
 for _ in range(n):
-    be.render(sc, shadows=True)
+    be.render(sc, shadows=True, counters=counters)
 print(be.last_stats)
