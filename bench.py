@@ -209,6 +209,9 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": int(kernel_alg[dominant]),
                          "avg_launch_ms": round(k_ms, 4), "launches_averaged": n_avg,
                          "frames_in_flight": args.frames_in_flight,
+                         "note": "avg_launch_ms is the event span of the kernel in the timed region, where it shares the "
+                                 "device with the kernels of the other frames in flight; solo_* is the same kernel on the "
+                                 "same frames rendered one at a time right after the timed region",
                          "solo_launch_ms": round(ktimes_solo[dominant], 4),
                          "solo_achieved": round(kernel_alg[dominant] / (ktimes_solo[dominant] * 1e-3) / 1e9, 2),
                          "solo_frac": round(kernel_alg[dominant] / (ktimes_solo[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
