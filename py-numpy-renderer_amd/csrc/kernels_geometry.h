@@ -162,7 +162,7 @@ __device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriR
         const TriClip &c = clips[t.face];
         double p[3];
         persp_bary(c.dp, u, v, w, single, p);
-        ok = inside_clip(p, c.clip) && inside_clip(p, c.clipd);
+        ok = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
     }
     return ok;
 }

@@ -497,7 +497,7 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
                     const TriClip &c = clips[f];
                     double p[3];
                     persp_bary(c.dp, u, v, w, single, p);
-                    in = inside_clip(p, c.clip) && inside_clip(p, c.clipd);
+                    in = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
                 }
             }
             const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,

@@ -250,8 +250,8 @@ k_shade(const FrameConst fc, const ShadeArgs a)
         persp_bary(a.clips[f].dp, u, v, w, false, p);
 
         double color[3];
-        if (mat.tex_kd >= 0) {
-            const float *tx = texel(a.textures[mat.tex_kd], a.uv, ti, p);
+        if (mat.map_kd.rgb) {
+            const float *tx = texel(mat.map_kd, a.uv, ti, p);
             color[0] = tx[0]; color[1] = tx[1]; color[2] = tx[2];
         } else {
             color[0] = mat.kd[0]; color[1] = mat.kd[1]; color[2] = mat.kd[2];
@@ -283,8 +283,8 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                 for (int j = 0; j < 3; ++j)
                     interp[j] = chain3(p[0], p[1], p[2], (double)n0[j], (double)n1[j], (double)n2[j]);
             }
-            if (mat.tex_norm >= 0) {
-                const float *tx = texel(a.textures[mat.tex_norm], a.uv, ti, p);
+            if (mat.map_norm.rgb) {
+                const float *tx = texel(mat.map_norm, a.uv, ti, p);
                 if (mat.norm_tangent) {
                     double n[3], A[3][3], AI[3][3];
                     c_normalize3(interp, n);
@@ -361,8 +361,8 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                 for (int j = 0; j < 3; ++j) color[j] = color[j] * in_light;
             }
             double spec_light[3];
-            if (mat.tex_ks >= 0) {
-                const float *tx = texel(a.textures[mat.tex_ks], a.uv, ti, p);
+            if (mat.map_ks.rgb) {
+                const float *tx = texel(mat.map_ks, a.uv, ti, p);
                 const float s = tx[0] * 255.0f;               // float32 product (obj/core.py:149)
                 spec_light[0] = spec_light[1] = spec_light[2] = (double)s;
             } else {

@@ -230,6 +230,11 @@ int commit(mr_scene *sc)
         HIP_TRY(hipMemcpy(sc->d_gamma.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     build_edge_table(sc);
+    for (mr::Material &m : sc->materials) {
+        const mr::Texture none = { nullptr, 0, 0 };
+        auto header = [&](int32_t id) { return id >= 0 && id < (int32_t)sc->textures.size() ? sc->textures[id] : none; };
+        m.map_kd = header(m.tex_kd); m.map_norm = header(m.tex_norm); m.map_ks = header(m.tex_ks);
+    }
     int rc;
     if ((rc = upload(sc->d_verts, sc->verts, g_stream))) return rc;
     if ((rc = upload(sc->d_uv, sc->uv, g_stream))) return rc;
@@ -300,6 +305,7 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
     std::memcpy(fc.sky_tri, fr->sky_tri, sizeof fc.sky_tri);
     std::memcpy(fc.sky_rays, fr->sky_rays, sizeof fc.sky_rays);
     fc.sky_size = sc->sky_size;
+    fc.same_clip = memcmp(fr->mvp, fr->debug_mvp, sizeof(fr->mvp)) == 0 ? 1 : 0;
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
     fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;

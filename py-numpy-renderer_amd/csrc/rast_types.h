@@ -57,7 +57,8 @@ struct FrameConst {
     float background[3];
     uint32_t background_u8;      // finalised background r | g << 8 | b << 16 | 1 << 24 (0 = not given)
     int32_t sky_tri[12];         // skybox triangles' integer screen vertices [t][v][xy]
-    int32_t sky_size, sky_pad;   // cubemap face size
+    int32_t sky_size;            // cubemap face size
+    int32_t same_clip;           // debug_mvp == mvp bit for bit: the second clip test repeats the first
     double sky_rays[18];         // their un-projected corner rays [t][v][xyz]
 };
 
@@ -113,16 +114,19 @@ struct alignas(16) QuadRec {
 };
 static_assert(sizeof(QuadRec) == 64 + 32 * MAX_POLY, "QuadRec layout");
 
+struct Texture {
+    const float *rgb;
+    int32_t h, w;
+};
+
 struct Material {
     double kd[3];
     double ks255[3];
     double ns;
     int32_t tex_kd, tex_norm, tex_ks, norm_tangent;
-};
-
-struct Texture {
-    const float *rgb;
-    int32_t h, w;
+    // the three maps' headers, copied in when the scene is committed (rgb == nullptr: no map), so
+    // that a pixel reaches its texel in one dependent load after the material instead of two
+    Texture map_kd, map_norm, map_ks;
 };
 
 // Device-side counters of one frame; copied back once at the end.
