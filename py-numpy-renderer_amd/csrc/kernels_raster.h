@@ -713,22 +713,28 @@ k_tile_quads(const FrameConst fc, const QuadRec *__restrict__ quads, const uint4
             if (!m) continue;
             qfrags += (unsigned int)__popcll(m);
             // Depth of the quad at the sample and the test against the z-buffer
-            // (obj/triangular.py:351-360).  The reference's value needs two IEEE divisions; the
-            // DECISION almost never does: an approximation good to 2e-10 (Newton-refined
-            // v_rcp_f64) settles it unless z-buffer and quad depth agree to nine digits, and
-            // only then is the exactly rounded expression evaluated.  Decisions stay bit-exact.
+            // (obj/triangular.py:351-360): zq = two_nf / (f_plus_n + (t / nz) * f_minus_n) with
+            // t the plane's value at the sample.  The reference's value needs two IEEE divisions;
+            // the DECISION needs none: multiplied through by nz, zbest - zq has the sign of
+            // E / D with D = f_plus_n * nz + t * f_minus_n and E = zbest * D - two_nf * nz.
+            // That settles it unless z-buffer and quad depth agree to nine digits or D is close
+            // to its pole (or something is not finite); only then is the exactly rounded
+            // expression evaluated.  t itself is computed exactly as the reference does.
+            // Decisions stay bit-exact.
             const uint4 p0 = rec[0], p1 = rec[1];
             const double q_nx = __hiloint2double((int)p0.y, (int)p0.x), q_ny = __hiloint2double((int)p0.w, (int)p0.z);
             const double nzq = __hiloint2double((int)p1.y, (int)p1.x), q_d = __hiloint2double((int)p1.w, (int)p1.z);
             const double t = (q_nx * dpx + q_ny * dpy) + q_d;
-            const double zs_a = -t * approx_rcp(nzq);
-            const double m_a = zs_a * fc.f_minus_n;
-            const double den_a = fc.f_plus_n - m_a;
-            const double zq_a = fc.two_nf * approx_rcp(den_a);
-            const double diff = zbest - zq_a;
-            bool pass = rh ? diff > 0 : diff < 0;
-            // not decided: close call, denominator near its pole, or a non-finite intermediate
-            const bool unsure = in && !(fabs(diff) > 2e-10 * fabs(zq_a) && fabs(den_a) > 2e-4 * fabs(m_a));
+            const double a0 = fc.f_plus_n * nzq, b0 = fc.two_nf * nzq;      // per quad
+            const double tf = t * fc.f_minus_n;
+            const double den = a0 + tf;
+            const double prod = zbest * den;
+            const double e = prod - b0;
+            // an empty z-buffer entry (+-inf) beats or loses against every finite depth
+            const bool zinf = fabs(zbest) == INFINITY;
+            bool pass = zinf ? (rh ? zbest > 0 : zbest < 0) : (rh ? ((e > 0) == (den > 0)) : ((e < 0) == (den > 0)));
+            const bool clear = zinf || fabs(e) > 1e-9 * (fabs(prod) + fabs(b0));
+            const bool unsure = in && !(clear && fabs(den) > 2e-4 * (fabs(a0) + fabs(tf)));
             if (__ballot(unsure)) {
                 if (unsure) {
                     const double z = linearize_z(fc, -t / nzq);
