@@ -52,18 +52,17 @@ __device__ __forceinline__ const float *texel(const Texture &tx, const float *uv
 // ---- colour-path arithmetic.  Coverage, z and texel indices above are bit-exact; the colour
 // that follows only has to land within +-1 uint8 of the reference (it already differs from it
 // in pow()), so its divisions and square roots use the hardware seeds (v_rcp_f64 / v_rsq_f64,
-// ~2^-23) refined by two Newton steps to ~1e-16 instead of the ~35-instruction IEEE
-// expansions: a lit pixel does some 30 divisions and 7 square roots.
+// good to ~2^-24) refined by ONE Newton step to ~1e-14 -- seven decimal orders below the
+// float32 the colour is stored in -- instead of the ~35-instruction IEEE expansions: a lit
+// pixel does some 30 divisions and 7 square roots.
 __device__ __forceinline__ double c_rcp(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
+    const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
 __device__ __forceinline__ double c_rsqrt(double x)
 {
-    double r = __builtin_amdgcn_rsq(x);
-    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    const double r = __builtin_amdgcn_rsq(x);
     return fma(0.5 * r, fma(-x * r, r, 1.0), r);
 }
 // normalize() of obj/transformation.py:46-49 (zero vectors stay zero)
