@@ -415,50 +415,6 @@ __device__ __forceinline__ double plane_dot(const double *P, const double *q)
     return chain4(P[0], P[1], P[2], P[3], q[0], q[1], q[2], q[3]);
 }
 
-// Sutherland-Hodgman against the six frustum planes, in the reference's order and with its
-// intersection formula p_next + t (p_cur - p_next) (obj/plane_intersection.py:24-36, 59-86).
-__device__ int clip_polygon(const double *planes, double (*poly)[4], int n)
-{
-    double tmp[MAX_POLY][4];
-    for (int pl = 0; pl < 6 && n > 0; ++pl) {
-        const double *P = planes + pl * 4;
-        // A plane that has every vertex on its visible side leaves the polygon untouched (the
-        // walk below would copy it verbatim), so it is skipped; a shadow quad is typically cut
-        // by the far plane only.
-        bool vis[MAX_POLY];
-        bool all = true;
-        for (int i = 0; i < n; ++i) { vis[i] = plane_dot(P, poly[i]) >= 0; all = all && vis[i]; }
-        if (all) continue;
-        int m = 0;
-        for (int i = 0; i < n; ++i) {
-            const int i1 = (i + 1 == n) ? 0 : i + 1;
-            const double *cur = poly[i];
-            const double *nxt = poly[i1];
-            const bool cv = vis[i], nv = vis[i1];
-            if (cv && m < MAX_POLY) {
-                for (int j = 0; j < 4; ++j) tmp[m][j] = cur[j];
-                ++m;
-            }
-            if (cv != nv && m < MAX_POLY) {
-                double dir[4];
-                for (int j = 0; j < 4; ++j) dir[j] = cur[j] - nxt[j];
-                double den = plane_dot(P, dir);
-                if (!(fabs(den) < 1e-10)) {
-                    double wgt = -plane_dot(P, nxt) / den;
-                    if (0 <= wgt && wgt <= 1) {
-                        for (int j = 0; j < 4; ++j) tmp[m][j] = nxt[j] + wgt * dir[j];
-                        ++m;
-                    }
-                }
-            }
-        }
-        n = m;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < 4; ++j) poly[i][j] = tmp[i][j];
-    }
-    return n;
-}
-
 // One thread per unique undirected edge of the scene.  An edge is on the silhouette when an
 // odd number of its incident light-facing faces toggled it; it keeps the orientation of the
 // last such face in face order (set add/discard semantics of obj/triangular.py:294-302).

@@ -444,9 +444,9 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                        fs->d_bin_count.as<uint32_t>(), fs->d_z.as<double>(), fs->d_winner.as<int32_t>(),
                        fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>());
     HIP_TRY(hipEventRecord(fs->ev[6], stream));
-    static const unsigned quad_grid = [] { const char *e = getenv("MR_QUAD_GRID"); return e ? (unsigned)atoi(e) : 4096u; }();
+    // grid-stride over the work items; 4096 workgroups (16 per CU) keep every CU's 6-8 slots refilled
     if (shadows)
-        hipLaunchKernelGGL(k_tile_quads, dim3(quad_grid), dim3(TILE_PX), 0, stream, fc, fs->d_quads.as<QuadRec>(),
+        hipLaunchKernelGGL(k_tile_quads, dim3(4096), dim3(TILE_PX), 0, stream, fc, fs->d_quads.as<QuadRec>(),
                            fs->d_quad_work.as<uint4>(), fs->quad_work_cap, fs->d_items.as<uint32_t>(), fs->item_cap,
                            fs->d_z.as<double>(), fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(),
                            fs->d_tile_stats.as<uint32_t>(), ctr);
