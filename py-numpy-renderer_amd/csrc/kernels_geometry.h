@@ -9,7 +9,7 @@
 //                 + obj/triangular.py:320-340 (extrusion, clip, projection, plane, box)
 #pragma once
 
-#include "rast_math.h"
+#include "kernels_bin.h"
 
 namespace mr {
 
@@ -167,14 +167,13 @@ __device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriR
     return ok;
 }
 
-__device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, Counters *ctr, int f, uint32_t flags,
-                                             int found, unsigned int covered)
+__device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, int f, uint32_t flags, int found)
 {
     if (found == 0) {
-        // the face never reaches the visibility kernel: account for its fragments here
-        // (the fragment count is taken before the clip, obj/triangular.py:78)
+        // The face was binned before this verdict (kernels_bin.h) and stays listed: the
+        // visibility kernel finds no surviving fragment for it and counts its covered ones
+        // (the fragment count is taken before the clip, obj/triangular.py:78).
         status[f] = FACE_CLIPPED;
-        if (covered) atomicAdd(&ctr->frag_tri, (unsigned long long)covered);
     } else if (found == 1) {
         tris[f].flags = flags | TF_SINGLE_Z;
     }
@@ -190,7 +189,7 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
                                              const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip,
                                              TriRec *__restrict__ tris, TriClip *__restrict__ clips,
                                              uint8_t *__restrict__ status, uint8_t *__restrict__ lit,
-                                             unsigned int &covered)
+                                             unsigned int &covered, PrimBox &pb, bool &clip)
 {
     const int32_t *fcx = faces + (size_t)f * 12;
     const int va = fcx[0], vb = fcx[4], vc = fcx[8];
@@ -221,6 +220,7 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
         return 0;
     }
     t.x0 = (int16_t)bx0; t.x1 = (int16_t)bx1; t.y0 = (int16_t)by0; t.y1 = (int16_t)by1;
+    pb = { bx0, bx1, by0, by1 };
     t.ax = A.sx; t.ay = A.sy;
     t.v0x = B.sx - A.sx; t.v0y = B.sy - A.sy;
     t.v1x = C.sx - A.sx; t.v1y = C.sy - A.sy;
@@ -234,6 +234,7 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
     t.pad[0] = t.pad[1] = 0;
     long long box = (long long)(bx1 - bx0) * (long long)(by1 - by0);
     const bool need_clip = (ff & FF_CLIP) && !(A.safe && B.safe && C.safe);
+    clip = need_clip;
     t.flags = (need_clip ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u) | ((uint32_t)ff << 8);   // bits 8-15: face flags, for k_shade
     t.face = f;
     if (box <= 0) { status[f] = FACE_CLIPPED; return 0; }    // no sample inside the box
@@ -283,7 +284,7 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
             const double *__restrict__ verts, const VertexOut *__restrict__ vout,
             const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris, TriClip *__restrict__ clips,
             uint8_t *__restrict__ status, uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list,
-            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr)
+            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr, const BinArgs bins)
 {
     constexpr int NW = SETUP_BLOCK / WAVE;
     __shared__ uint32_t s_valid[NW], s_count[NW], s_covered;
@@ -291,9 +292,13 @@ k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     if (threadIdx.x == 0) s_covered = 0;
     unsigned int covered = 0;
+    PrimBox pb = { 0, 0, 0, 0 };
+    bool clip = false;
     const int r = f < fc.n_faces ? tri_setup_one(fc, f, faces, face_flags, verts, vout, vclip, tris, clips,
-                                                 status, lit, covered)
+                                                 status, lit, covered, pb, clip)
                                  : 0;
+    // count pass of the binning for the faces that go on (kernels_bin.h)
+    bin_triangles<false>(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);
     const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);
     if (lane == 0) { s_valid[wv] = (uint32_t)__popcll(bv); s_count[wv] = (uint32_t)__popcll(bc); }
     __syncthreads();
@@ -341,15 +346,13 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
         cx = min(max(cx, (int)tb.x0), tb.x1 - 1); cy = min(max(cy, (int)tb.y0), tb.y1 - 1);
         const long long first = ((long long)(cy - tb.y0) * w + (cx - tb.x0)) / WAVE;
         int found = 0;
-        unsigned int covered = 0;
         for (long long c = 0; c < chunks && found < 2; ++c) {
             const long long idx = ((first + c) % chunks) * WAVE + lane;
             bool cov = false, ok = false;
             if (idx < n) ok = sample_survives(fc, tb, clips, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w), cov);
-            covered += (unsigned int)__popcll(__ballot(cov));
             found += __popcll(__ballot(ok));
         }
-        if (lane == 0) count_finish(tris, status, ctr, fb, tb.flags, found, covered);
+        if (lane == 0) count_finish(tris, status, fb, tb.flags, found);
     }
 }
 
@@ -483,7 +486,7 @@ __device__ __forceinline__ double shfl_d(double v, int src)
 
 __global__ void __launch_bounds__(64)
 k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const double *__restrict__ verts,
-             QuadRec *__restrict__ quads, uint32_t quad_cap, Counters *__restrict__ ctr)
+             QuadRec *__restrict__ quads, uint32_t quad_cap, Counters *__restrict__ ctr, const BinArgs bins)
 {
     __shared__ double s_poly[WAVE / QS_LANES][MAX_POLY + 4][4];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -600,6 +603,9 @@ k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const d
     uint32_t slot = 0;
     if (boxed && gl == 0) slot = atomicAdd(&ctr->n_quads_drawn, 1u);
     slot = (uint32_t)__shfl((int)slot, g0);
+    // count pass of the binning: the quad as work items of 64 tiles (kernels_bin.h); all lanes take part
+    push_work_items(bins, WORK_QUAD | slot,
+                    (boxed && gl == 0 && slot < quad_cap) ? quad_chunks(fc, bx0, bx1, by0, by1) : 0u);
     if (!boxed) continue;
     if (slot >= quad_cap) { if (gl == 0) atomicOr(&ctr->overflow, 4u); continue; }
 

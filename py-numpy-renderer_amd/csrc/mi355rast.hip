@@ -4,8 +4,8 @@
 // arrays, textures, the unique-edge table for silhouettes) resident in HBM; a frame is a fixed
 // sequence of kernels on one HIP stream, with no host synchronisation in between:
 //
-//   k_vertex -> k_tri_setup -> k_tri_count -> [k_silhouette -> k_quad_setup]
-//     -> k_bin_classify<count> -> k_bin_large<count> -> k_scan_bins -> k_bin_classify<fill> -> k_bin_large<fill>
+//   k_vertex_mfma -> k_tri_setup (+ bin count of its faces) -> k_silhouette_and_count
+//     -> [k_quad_setup (+ work items of its quads)] -> k_bin_large (count) -> k_scan_bins -> k_bin_fill
 //     -> k_tile_raster -> [k_tile_quads] -> k_shade -> (D2H of the uint8 band for mr_render)
 //
 // Per-frame work buffers live in a "frame slot".  Every stream a caller renders on gets its own
@@ -388,12 +388,21 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     else
         hipLaunchKernelGGL(k_vertex_mfma, dim3(blocks_for(fc.n_vertices, 64)), dim3(256), 0, stream, fc,
                            sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr);
+    // binning arguments (kernels_bin.h): k_tri_setup and k_quad_setup run its count pass for their primitives
+    BinArgs ba;
+    ba.tris = fs->d_tris.as<TriRec>(); ba.valid_list = fs->d_valid.as<uint32_t>();
+    ba.quads = fs->d_quads.as<QuadRec>();
+    ba.ctr = ctr; ba.quad_cap = fs->quad_cap;
+    ba.bin_count = fs->d_bin_count.as<uint32_t>(); ba.bin_offset = fs->d_bin_offset.as<uint32_t>();
+    ba.items = fs->d_items.as<uint32_t>(); ba.item_cap = fs->item_cap;
+    ba.work = fs->d_work.as<uint2>(); ba.work_cap = fs->work_cap;
+    ba.quad_work = fs->d_quad_work.as<uint4>(); ba.quad_work_cap = fs->quad_work_cap;
     if (fc.n_faces > 0)
         hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, SETUP_BLOCK)), dim3(SETUP_BLOCK), 0, stream, fc,
                            sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
                            fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), fs->d_tris.as<TriRec>(),
                            fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), fs->d_lit.as<uint8_t>(),
-                           fs->d_valid.as<uint32_t>(), fs->d_count_list.as<uint32_t>(), ctr);
+                           fs->d_valid.as<uint32_t>(), fs->d_count_list.as<uint32_t>(), ctr, ba);
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
     {
         // silhouette detection and the leftover survivor counts are independent: one launch
@@ -411,30 +420,21 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         const long long max_sil = std::min<long long>(fc.n_edges, fs->quad_cap);
         hipLaunchKernelGGL(k_quad_setup, dim3((unsigned)std::min<long long>(1024, blocks_for(max_sil * QS_LANES, 64))),
                            dim3(64), 0, stream, fc, fs->d_sil.as<int32_t>(), sc->d_verts.as<double>(),
-                           fs->d_quads.as<QuadRec>(), fs->quad_cap, ctr);
+                           fs->d_quads.as<QuadRec>(), fs->quad_cap, ctr, ba);
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[3], stream));
 
-    // ---- binning: classify + count, large-primitive count, scan, fill, large-primitive fill
-    BinArgs ba;
-    ba.tris = fs->d_tris.as<TriRec>(); ba.valid_list = fs->d_valid.as<uint32_t>();
-    ba.status = fs->d_status.as<uint8_t>(); ba.quads = fs->d_quads.as<QuadRec>();
-    ba.ctr = ctr; ba.quad_cap = fs->quad_cap;
-    ba.bin_count = fs->d_bin_count.as<uint32_t>(); ba.bin_offset = fs->d_bin_offset.as<uint32_t>();
-    ba.items = fs->d_items.as<uint32_t>(); ba.item_cap = fs->item_cap;
-    ba.work = fs->d_work.as<uint2>(); ba.work_cap = fs->work_cap;
-    ba.quad_work = fs->d_quad_work.as<uint4>(); ba.quad_work_cap = fs->quad_work_cap;
-    const long long n_prims_max = (long long)fc.n_faces + (shadows ? std::min<long long>(fc.n_edges, fs->quad_cap) : 0);
-    const unsigned classify_blocks = blocks_for(std::max<long long>(n_prims_max, n_tiles), 256);
+    // ---- binning (the count of the primitives' own tiles happened in k_tri_setup / k_quad_setup):
+    // count of the large primitives' work items, scan, fill
+    const unsigned list_blocks = blocks_for(std::max<long long>(fc.n_faces, n_tiles), 256);
     const unsigned large_blocks = 512;       // grid-stride over the work items, 4 wavefronts per block
-    hipLaunchKernelGGL((k_bin_classify<false>), dim3(classify_blocks), dim3(256), 0, stream, fc, ba);
-    hipLaunchKernelGGL((k_bin_large<false>), dim3(large_blocks), dim3(256), 0, stream, fc, ba);
+    hipLaunchKernelGGL(k_bin_large, dim3(large_blocks), dim3(256), 0, stream, fc, ba);
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[4], stream));
     hipLaunchKernelGGL(k_scan_bins, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, stream, fs->d_bin_count.as<uint32_t>(),
                        fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr,
                        fs->d_scan_part.as<unsigned long long>(), (uint32_t)(fs->frames_enqueued % 0xfffffffeull) + 1u);
-    hipLaunchKernelGGL(k_bin_fill, dim3(classify_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
-                       classify_blocks, large_blocks);
+    hipLaunchKernelGGL(k_bin_fill, dim3(list_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
+                       list_blocks, large_blocks);
     HIP_TRY(hipEventRecord(fs->ev[5], stream));
 
     // ---- visibility: coverage, z, winner; then the shadow volumes' stencil counts
