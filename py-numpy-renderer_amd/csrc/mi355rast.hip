@@ -407,7 +407,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     {
         // silhouette detection and the leftover survivor counts are independent: one launch
         const unsigned sil_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, 256) : 0u;
-        const unsigned count_blocks = fc.n_faces > 0 ? std::min(128u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
+        // one wavefront per listed face, grid-stride; 512 workgroups: a mesh of large faces lists most of them (c2/c3: 128 -> 512 workgroups took 3 us off)
+        const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
         if (sil_blocks + count_blocks > 0)
             hipLaunchKernelGGL(k_silhouette_and_count, dim3(sil_blocks + count_blocks), dim3(256), 0, stream, fc,
                                sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
