@@ -229,6 +229,7 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
 // the order of the quads never mattered: obj/triangular.py:365-368).
 constexpr int QUAD_STAGE_U4 = 12;     // uint4 pieces staged per quad: 64-byte header + 4 edges
 static_assert(offsetof(QuadRec, e) == 64 && sizeof(QuadEdge) == 32, "QuadRec layout");
+static_assert(QUAD_BATCH * QUAD_STAGE_U4 <= TILE_PX, "one lane stages one 16-byte piece of the item's records");
 
 struct QuadHead {                     // the first 64 bytes of a QuadRec, as staged
     double nx, ny, nz, d;
