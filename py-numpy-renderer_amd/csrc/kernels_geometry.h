@@ -219,6 +219,9 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
         status[f] = FACE_EMPTY_Z;
         return 0;
     }
+    // a device that renders a band of rows drops the faces whose pixel box misses the band right
+    // here (their light-facing flag above is still needed: silhouettes are found on the whole mesh)
+    if (by1 <= fc.band_y0 || by0 >= fc.band_y1) { status[f] = FACE_CLIPPED; return 0; }
     t.x0 = (int16_t)bx0; t.x1 = (int16_t)bx1; t.y0 = (int16_t)by0; t.y1 = (int16_t)by1;
     pb = { bx0, bx1, by0, by1 };
     t.ax = A.sx; t.ay = A.sy;
