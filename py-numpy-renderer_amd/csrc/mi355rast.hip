@@ -346,6 +346,10 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     HIP_TRY(fs->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
     HIP_TRY(fs->d_bin_offset.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
     const int scan_blocks = blocks_for(BIN_CLASSES * n_tiles, SCAN_ITEMS) > 0 ? blocks_for(BIN_CLASSES * n_tiles, SCAN_ITEMS) : 1;
+    // k_scan_bins' workgroups wait for their predecessors' totals, so all of them must be able to be
+    // resident at once (256 CUs x 8): beyond ~350 000 tiles (a 9 400 x 9 400 px band) render in row bands
+    if (scan_blocks > 1024)
+        return fail(MR_E_UNSUPPORTED, "band too large for one pass (more than 349 525 tiles of 16x16 px): render it in row bands");
     {
         const void *had = fs->d_scan_part.p;
         HIP_TRY(fs->d_scan_part.ensure((size_t)scan_blocks * 8));
