@@ -233,7 +233,7 @@ k_bin_large(const FrameConst fc, const BinArgs a) { bin_large_body<false>(fc, a,
 // tile u, cut each tile's shadow-quad list into work items of at most QUAD_BATCH quads for
 // k_tile_quads, so that the tiles under a dense shadow volume are shared out over many workgroups.
 __global__ void __launch_bounds__(256)
-k_bin_fill(const FrameConst fc, const BinArgs a, uint32_t list_blocks, uint32_t large_blocks)
+k_bin_fill(const FrameConst fc, const BinArgs a, uint32_t large_blocks)
 {
     if (blockIdx.x < large_blocks) { bin_large_body<true>(fc, a, blockIdx.x, large_blocks); return; }
     const uint32_t u = (blockIdx.x - large_blocks) * blockDim.x + threadIdx.x;

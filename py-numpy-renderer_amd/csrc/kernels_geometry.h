@@ -148,7 +148,6 @@ __device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *
 
 // Survivors of coverage + clip among the first `limit` samples of a triangle's pixel box, as
 // seen by one lane walking the box sample by sample (stops at two).
-struct CountResult { int found; unsigned int covered; };
 
 __device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const TriClip *clips,
                                                 int px, int py, bool &covered_in_band)
@@ -457,7 +456,7 @@ k_silhouette_and_count(const FrameConst fc, const uint32_t *__restrict__ edge_of
                        const uint8_t *__restrict__ lit, int32_t *__restrict__ sil_edges, uint32_t quad_cap,
                        const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
                        const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
-                       Counters *__restrict__ ctr, uint32_t sil_blocks, uint32_t count_blocks)
+                       Counters *__restrict__ ctr, uint32_t count_blocks)
 {
     // the few counting workgroups come first so that their (latency-bound) work is in flight
     // while the silhouette workgroups are still being dispatched

@@ -63,9 +63,8 @@ __device__ __forceinline__ double z_unkey(unsigned long long k)
 constexpr int SMALL_LANES = 4;
 
 template <int SWEEP>
-__device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, const TriClip *clips,
-                                           int gx, int gy, bool rh, unsigned long long *s_key, int *s_win,
-                                           int sub, unsigned int &frags)
+__device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, int gx, int gy, bool rh,
+                                           unsigned long long *s_key, int *s_win, int sub, unsigned int &frags)
 {
     const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
     const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
@@ -103,7 +102,7 @@ __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t
 // owned the mesh and its shadow (measured: 330 workgroups resident on average).
 __global__ void __launch_bounds__(TILE_PX)
 k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriClip *__restrict__ clips,
-              const QuadRec *__restrict__ quads, const uint32_t *__restrict__ bin_offset,
+              const uint32_t *__restrict__ bin_offset,
               const uint32_t *__restrict__ items, uint32_t item_cap, uint32_t *__restrict__ bin_count,
               double *__restrict__ zbuf, int32_t *__restrict__ winner, int32_t *__restrict__ stencil,
               uint32_t *__restrict__ tile_stats)
@@ -181,7 +180,7 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
     unsigned int sfrags = 0;
     for (uint32_t i = sbeg + tid / SMALL_LANES; i < send; i += TILE_PX / SMALL_LANES) {
         const TriRec t = tris[items[i]];
-        small_pair<0>(fc, t, clips, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+        small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
     }
     if (sfrags) atomicAdd(&s_cnt[0], sfrags);
     __syncthreads();
@@ -192,7 +191,7 @@ k_tile_raster(const FrameConst fc, const TriRec *__restrict__ tris, const TriCli
     __syncthreads();
     for (uint32_t i = sbeg + tid / SMALL_LANES; i < send; i += TILE_PX / SMALL_LANES) {
         const TriRec t = tris[items[i]];
-        small_pair<1>(fc, t, clips, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+        small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
     }
     __syncthreads();
     best = s_win[lp];

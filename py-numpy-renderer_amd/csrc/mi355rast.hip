@@ -418,7 +418,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                                sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
                                fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap,
                                fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                               fs->d_status.as<uint8_t>(), ctr, sil_blocks, count_blocks);
+                               fs->d_status.as<uint8_t>(), ctr, count_blocks);
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
     if (shadows && fc.n_edges > 0) {
@@ -438,13 +438,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     hipLaunchKernelGGL(k_scan_bins, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, stream, fs->d_bin_count.as<uint32_t>(),
                        fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr,
                        fs->d_scan_part.as<unsigned long long>(), (uint32_t)(fs->frames_enqueued % 0xfffffffeull) + 1u);
-    hipLaunchKernelGGL(k_bin_fill, dim3(list_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
-                       list_blocks, large_blocks);
+    hipLaunchKernelGGL(k_bin_fill, dim3(list_blocks + large_blocks), dim3(256), 0, stream, fc, ba, large_blocks);
     HIP_TRY(hipEventRecord(fs->ev[5], stream));
 
     // ---- visibility: coverage, z, winner; then the shadow volumes' stencil counts
     hipLaunchKernelGGL(k_tile_raster, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc,
-                       fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(), fs->d_quads.as<QuadRec>(),
+                       fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
                        fs->d_bin_offset.as<uint32_t>(), fs->d_items.as<uint32_t>(), fs->item_cap,
                        fs->d_bin_count.as<uint32_t>(), fs->d_z.as<double>(), fs->d_winner.as<int32_t>(),
                        fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>());
