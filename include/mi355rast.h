@@ -180,8 +180,9 @@ int mr_get_stats(mr_scene *scene, mr_stats *stats);
 
 /* Average device time in milliseconds (HIP events on the stream the kernels ran on) of each
  * stage over the last n_frames frames, most recent first; at most 128 are remembered.
- *   [0] k_vertex + k_tri_setup     [1] k_tri_count     [2] k_silhouette + k_quad_setup
- *   [3] binning, count passes      [4] binning, scan + fill passes
+ *   [0] vertex transform + light-facing flags     [1] face set-up (+ its bin counts) + silhouette search
+ *   [2] shadow-quad set-up         [3] bin count of the work items + leftover survivor counts
+ *   [4] binning, scan + fill passes
  *   [5] k_tile_raster              [6] k_tile_quads    [7] k_shade
  *   [8] whole frame (start -> after k_shade)
  * Frames rendered with MR_FRAME_LIGHT_TIMING report [0..4] as 0.

@@ -261,7 +261,7 @@ class DeviceRenderer:
         self.last_stats = st.as_dict()
         return self.last_stats
 
-    KERNEL_TIME_NAMES = ("vertex+tri_setup", "tri_count", "silhouette+quad_setup", "bin_count", "bin_scan_fill",
+    KERNEL_TIME_NAMES = ("vertex+lit", "tri_setup+silhouette", "quad_setup", "bin_large+tri_count", "bin_scan_fill",
                          "tile_raster", "tile_quads", "shade", "frame")
 
     def kernel_times(self, n_frames):

@@ -5,7 +5,8 @@
 //                    counts of the <= BIN_SMALL tiles it touches (bin_count_triangles); a face
 //                    that spans more tiles is cut into work items of 64 tiles
 //   k_quad_setup     every shadow quad is cut into work items of 64 tiles
-//   k_bin_large      count pass of the work items: one wavefront per item, one tile per lane
+//   k_bin_large_and_count   (kernels_geometry.h) count pass of the work items: one wavefront per
+//                    item, one tile per lane
 //   k_scan_bins      exclusive scan of the per-(class, tile) counts
 //   k_bin_fill       the same enumeration again, now writing the item array: small triangles
 //                    from the list of set-up faces, everything else from the work items
@@ -224,9 +225,6 @@ __device__ __forceinline__ void bin_large_body(const FrameConst &fc, const BinAr
             bin_emit<FILL>(fc, a, pair_class(fc, is_quad, clip, pb, tx, ty), id, tx, ty);
     }
 }
-
-__global__ void __launch_bounds__(256)
-k_bin_large(const FrameConst fc, const BinArgs a) { bin_large_body<false>(fc, a, blockIdx.x, gridDim.x); }
 
 // Fill pass in one launch: workgroups [0, large_blocks) fill from the work items, the rest walk
 // the list of set-up faces (small triangles only; the others were work items) and, thread u for

@@ -13,10 +13,56 @@
 
 namespace mr {
 
+// unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130),
+// dotted with light.position (obj/triangular.py:295)
+__device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *a, const double *b,
+                                            const double *c, bool verts_f32)
+{
+    double n[3];
+    if (verts_f32) {
+        float e0[3], e1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            e0[j] = (float)b[j] - (float)a[j];
+            e1[j] = (float)c[j] - (float)a[j];
+        }
+        float cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                        e0[0] * e1[1] - e0[1] * e1[0] };
+        float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+        if (l == 0) l = 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n[j] = (double)(cr[j] / l);
+    } else {
+        double e0[3], e1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { e0[j] = b[j] - a[j]; e1[j] = c[j] - a[j]; }
+        double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                         e0[0] * e1[1] - e0[1] * e1[0] };
+        normalize3(cr, n);
+    }
+    return chain3(n[0], n[1], n[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0;
+}
+
+// Light-facing flag of every face (input of the silhouette search), thread per face.  It only
+// needs the static mesh and the light, so it rides along with the vertex transform as extra
+// workgroups of the frame's first launch instead of lengthening k_tri_setup.
+__device__ __forceinline__ void lit_body(const FrameConst &fc, const int32_t *__restrict__ faces,
+                                         const uint8_t *__restrict__ face_flags, const double *__restrict__ verts,
+                                         uint8_t *__restrict__ lit, uint32_t block)
+{
+    const int f = (int)(block * blockDim.x + threadIdx.x);
+    if (f >= fc.n_faces) return;
+    const int32_t *fcx = faces + (size_t)f * 12;
+    lit[f] = faces_light(fc, verts + (size_t)fcx[0] * 4, verts + (size_t)fcx[4] * 4, verts + (size_t)fcx[8] * 4,
+                         (face_flags[f] & FF_VERTS_F32) != 0) ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256)
 k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
-         VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr)
+         VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr, const int32_t *__restrict__ faces,
+         const uint8_t *__restrict__ face_flags, uint8_t *__restrict__ lit, uint32_t vertex_blocks)
 {
+    if (blockIdx.x >= vertex_blocks) { lit_body(fc, faces, face_flags, verts, lit, blockIdx.x - vertex_blocks); return; }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *ctr = Counters{};      // first kernel of the frame: every later one is stream-ordered after it
     if (i >= fc.n_vertices) return;
@@ -64,8 +110,10 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
-              VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr)
+              VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr, const int32_t *__restrict__ faces,
+              const uint8_t *__restrict__ face_flags, uint8_t *__restrict__ lit, uint32_t vertex_blocks)
 {
+    if (blockIdx.x >= vertex_blocks) { lit_body(fc, faces, face_flags, verts, lit, blockIdx.x - vertex_blocks); return; }
     __shared__ double s_clip[4][16][8];     // per wavefront: [vertex][MVP x,y,z,w | debug x,y,z,w]
     __shared__ double s_scr[4][16][4];      // per wavefront: [vertex][screen x, y, z]
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
@@ -116,36 +164,6 @@ k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *
     }
 }
 
-// unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130),
-// dotted with light.position (obj/triangular.py:295)
-__device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *a, const double *b,
-                                            const double *c, bool verts_f32)
-{
-    double n[3];
-    if (verts_f32) {
-        float e0[3], e1[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            e0[j] = (float)b[j] - (float)a[j];
-            e1[j] = (float)c[j] - (float)a[j];
-        }
-        float cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
-                        e0[0] * e1[1] - e0[1] * e1[0] };
-        float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
-        if (l == 0) l = 1;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) n[j] = (double)(cr[j] / l);
-    } else {
-        double e0[3], e1[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { e0[j] = b[j] - a[j]; e1[j] = c[j] - a[j]; }
-        double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
-                         e0[0] * e1[1] - e0[1] * e1[0] };
-        normalize3(cr, n);
-    }
-    return chain3(n[0], n[1], n[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0;
-}
-
 // Survivors of coverage + clip among the first `limit` samples of a triangle's pixel box, as
 // seen by one lane walking the box sample by sample (stops at two).
 
@@ -184,19 +202,14 @@ constexpr int COUNT_SMALL_BOX = 32;   // pixel boxes up to this size are walked 
 // the visibility kernel, bit 1 = its survivor count is left to k_tri_count; `covered` receives
 // the fragments of a face settled as CLIPPED right here.
 __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const int32_t *__restrict__ faces,
-                                             const uint8_t *__restrict__ face_flags, const double *__restrict__ verts,
+                                             const uint8_t *__restrict__ face_flags,
                                              const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip,
                                              TriRec *__restrict__ tris, TriClip *__restrict__ clips,
-                                             uint8_t *__restrict__ status, uint8_t *__restrict__ lit,
-                                             unsigned int &covered, PrimBox &pb, bool &clip)
+                                             uint8_t *__restrict__ status, unsigned int &covered, PrimBox &pb, bool &clip)
 {
     const int32_t *fcx = faces + (size_t)f * 12;
     const int va = fcx[0], vb = fcx[4], vc = fcx[8];
     const uint8_t ff = face_flags[f];
-
-    if (fc.flags & MR_FRAME_SHADOWS)
-        lit[f] = faces_light(fc, verts + (size_t)va * 4, verts + (size_t)vb * 4, verts + (size_t)vc * 4,
-                             (ff & FF_VERTS_F32) != 0) ? 1 : 0;
 
     const VertexOut A = vout[va], B = vout[vb], C = vout[vc];
 
@@ -218,8 +231,7 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
         status[f] = FACE_EMPTY_Z;
         return 0;
     }
-    // a device that renders a band of rows drops the faces whose pixel box misses the band right
-    // here (their light-facing flag above is still needed: silhouettes are found on the whole mesh)
+    // a device that renders a band of rows drops the faces whose pixel box misses the band right here
     if (by1 <= fc.band_y0 || by0 >= fc.band_y1) { status[f] = FACE_CLIPPED; return 0; }
     t.x0 = (int16_t)bx0; t.x1 = (int16_t)bx1; t.y0 = (int16_t)by0; t.y1 = (int16_t)by1;
     pb = { bx0, bx1, by0, by1 };
@@ -281,23 +293,21 @@ constexpr int SETUP_BLOCK = 512;
 // settle) are appended to with ONE atomic per workgroup and list: the frame's counters share a
 // cache line, and same-line atomics retire at only ~0.3 per ns on MI355X
 // (tools/micro/atomic_bench.hip), so per-wavefront appends alone cost more than the set-up.
-__global__ void __launch_bounds__(SETUP_BLOCK)
-k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
-            const double *__restrict__ verts, const VertexOut *__restrict__ vout,
-            const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris, TriClip *__restrict__ clips,
-            uint8_t *__restrict__ status, uint8_t *__restrict__ lit, uint32_t *__restrict__ valid_list,
-            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr, const BinArgs bins)
+__device__ __forceinline__ void
+tri_setup_block(const FrameConst &fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
+                const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris,
+                TriClip *__restrict__ clips, uint8_t *__restrict__ status, uint32_t *__restrict__ valid_list,
+                uint32_t *__restrict__ count_list, Counters *__restrict__ ctr, const BinArgs &bins, uint32_t block)
 {
     constexpr int NW = SETUP_BLOCK / WAVE;
     __shared__ uint32_t s_valid[NW], s_count[NW], s_covered;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = block * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     if (threadIdx.x == 0) s_covered = 0;
     unsigned int covered = 0;
     PrimBox pb = { 0, 0, 0, 0 };
     bool clip = false;
-    const int r = f < fc.n_faces ? tri_setup_one(fc, f, faces, face_flags, verts, vout, vclip, tris, clips,
-                                                 status, lit, covered, pb, clip)
+    const int r = f < fc.n_faces ? tri_setup_one(fc, f, faces, face_flags, vout, vclip, tris, clips, status, covered, pb, clip)
                                  : 0;
     // count pass of the binning for the faces that go on (kernels_bin.h)
     bin_triangles<false>(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);
@@ -447,23 +457,38 @@ silhouette_body(const FrameConst &fc, const uint32_t *__restrict__ edge_offset, 
     }
 }
 
-// Two independent stages that both follow k_tri_setup share one launch (a launch of a nearly
-// empty kernel costs ~10 us of latency on its own): workgroups [0, count_blocks) settle the
-// survivor counts k_tri_setup left open, the remaining sil_blocks detect silhouette edges.
-__global__ void __launch_bounds__(256)
-k_silhouette_and_count(const FrameConst fc, const uint32_t *__restrict__ edge_offset,
-                       const uint32_t *__restrict__ edge_inc, const int32_t *__restrict__ faces,
-                       const uint8_t *__restrict__ lit, int32_t *__restrict__ sil_edges, uint32_t quad_cap,
-                       const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
-                       const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
-                       Counters *__restrict__ ctr, uint32_t count_blocks)
+// The set-up of the faces and the silhouette search are independent (both read what the frame's
+// first launch wrote: screen-space vertices, light-facing flags), so they share a launch:
+// workgroups [0, setup_blocks) set faces up, the rest look for silhouette edges.  The leftover
+// survivor counts ride with the count pass of the large primitives' work items further down
+// the chain (nothing before the visibility kernel needs their verdict).  A nearly empty kernel
+// costs ~10 us of latency on its own, and under several frames in flight each stream spends a
+// third of its time between dependent kernels: every launch the chain loses is time gained.
+__global__ void __launch_bounds__(SETUP_BLOCK)
+k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
+            const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris,
+            TriClip *__restrict__ clips, uint8_t *__restrict__ status, uint32_t *__restrict__ valid_list,
+            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr, const BinArgs bins, uint32_t setup_blocks,
+            const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
+            const uint8_t *__restrict__ lit, int32_t *__restrict__ sil_edges, uint32_t quad_cap)
 {
-    // the few counting workgroups come first so that their (latency-bound) work is in flight
-    // while the silhouette workgroups are still being dispatched
+    if (blockIdx.x < setup_blocks)
+        tri_setup_block(fc, faces, face_flags, vout, vclip, tris, clips, status, valid_list, count_list, ctr, bins, blockIdx.x);
+    else
+        silhouette_body(fc, edge_offset, edge_inc, faces, lit, sil_edges, quad_cap, ctr, blockIdx.x - setup_blocks);
+}
+
+// Count pass of the work items (large faces, shadow quads) and the leftover survivor counts: the
+// few counting workgroups come first so that their latency-bound work is in flight early.
+__global__ void __launch_bounds__(256)
+k_bin_large_and_count(const FrameConst fc, const BinArgs bins, const uint32_t *__restrict__ count_list,
+                      TriRec *__restrict__ tris, const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
+                      Counters *__restrict__ ctr, uint32_t count_blocks)
+{
     if (blockIdx.x < count_blocks)
         tri_count_body(fc, count_list, tris, clips, status, ctr, blockIdx.x, count_blocks);
     else
-        silhouette_body(fc, edge_offset, edge_inc, faces, lit, sil_edges, quad_cap, ctr, blockIdx.x - count_blocks);
+        bin_large_body<false>(fc, bins, blockIdx.x - count_blocks, gridDim.x - count_blocks);
 }
 
 // Shadow-quad set-up: extrusion away from the light, Sutherland-Hodgman clipping against the

@@ -4,8 +4,8 @@
 // arrays, textures, the unique-edge table for silhouettes) resident in HBM; a frame is a fixed
 // sequence of kernels on one HIP stream, with no host synchronisation in between:
 //
-//   k_vertex_mfma -> k_tri_setup (+ bin count of its faces) -> k_silhouette_and_count
-//     -> [k_quad_setup (+ work items of its quads)] -> k_bin_large (count) -> k_scan_bins -> k_bin_fill
+//   k_vertex_mfma (+ light-facing flags) -> k_tri_setup (+ bin count of its faces; + silhouette search)
+//     -> [k_quad_setup (+ work items of its quads)] -> k_bin_large_and_count -> k_scan_bins -> k_bin_fill
 //     -> k_tile_raster -> [k_tile_quads] -> k_shade -> (D2H of the uint8 band for mr_render)
 //
 // Per-frame work buffers live in a "frame slot".  Every stream a caller renders on gets its own
@@ -79,7 +79,7 @@ struct EdgeKey {
 };
 
 // Event marks of one frame:
-//   0 start | 1 vertex+tri_setup | 2 tri_count | 3 silhouette+quad_setup | 4 bin count passes |
+//   0 start | 1 vertex + light flags | 2 face set-up + silhouettes | 3 quad set-up | 4 work-item count + survivor counts |
 //   5 bin scan+fill | 6 tile raster | 7 tile quads | 8 shade | 9 device->host copy
 constexpr int EVENT_RING = 64, N_MARKS = 10;
 
@@ -384,14 +384,22 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
 
     // ---- geometry
     // vertex transform on the matrix cores (v_mfma_f64_16x16x4_f64, 16 vertices per wavefront);
-    // MR_VERTEX_PATH=valu selects the VALU fma-chain kernel instead (same bits, for A/B timing)
+    // MR_VERTEX_PATH=valu selects the VALU fma-chain kernel instead (same bits, for A/B timing).
+    // The light-facing flags of the faces (for the silhouettes) are extra workgroups of this launch.
     static const bool vertex_valu = [] { const char *e = getenv("MR_VERTEX_PATH"); return e && !strcmp(e, "valu"); }();
-    if (vertex_valu)
-        hipLaunchKernelGGL(k_vertex, dim3(blocks_for(fc.n_vertices, 256)), dim3(256), 0, stream, fc,
-                           sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr);
-    else
-        hipLaunchKernelGGL(k_vertex_mfma, dim3(blocks_for(fc.n_vertices, 64)), dim3(256), 0, stream, fc,
-                           sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr);
+    const unsigned lit_blocks = (shadows && fc.n_faces > 0) ? blocks_for(fc.n_faces, 256) : 0u;
+    if (vertex_valu) {
+        const unsigned vb = blocks_for(fc.n_vertices, 256);
+        hipLaunchKernelGGL(k_vertex, dim3(vb + lit_blocks), dim3(256), 0, stream, fc, sc->d_verts.as<double>(),
+                           fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr, sc->d_faces.as<int32_t>(),
+                           sc->d_face_flags.as<uint8_t>(), fs->d_lit.as<uint8_t>(), vb);
+    } else {
+        const unsigned vb = blocks_for(fc.n_vertices, 64);
+        hipLaunchKernelGGL(k_vertex_mfma, dim3(vb + lit_blocks), dim3(256), 0, stream, fc, sc->d_verts.as<double>(),
+                           fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr, sc->d_faces.as<int32_t>(),
+                           sc->d_face_flags.as<uint8_t>(), fs->d_lit.as<uint8_t>(), vb);
+    }
+    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
     // binning arguments (kernels_bin.h): k_tri_setup and k_quad_setup run its count pass for their primitives
     BinArgs ba;
     ba.tris = fs->d_tris.as<TriRec>(); ba.valid_list = fs->d_valid.as<uint32_t>();
@@ -401,24 +409,18 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ba.items = fs->d_items.as<uint32_t>(); ba.item_cap = fs->item_cap;
     ba.work = fs->d_work.as<uint2>(); ba.work_cap = fs->work_cap;
     ba.quad_work = fs->d_quad_work.as<uint4>(); ba.quad_work_cap = fs->quad_work_cap;
-    if (fc.n_faces > 0)
-        hipLaunchKernelGGL(k_tri_setup, dim3(blocks_for(fc.n_faces, SETUP_BLOCK)), dim3(SETUP_BLOCK), 0, stream, fc,
-                           sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(),
-                           fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), fs->d_tris.as<TriRec>(),
-                           fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), fs->d_lit.as<uint8_t>(),
-                           fs->d_valid.as<uint32_t>(), fs->d_count_list.as<uint32_t>(), ctr, ba);
-    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
     {
-        // silhouette detection and the leftover survivor counts are independent: one launch
-        const unsigned sil_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, 256) : 0u;
-        // one wavefront per listed face, grid-stride; 512 workgroups: a mesh of large faces lists most of them (c2/c3: 128 -> 512 workgroups took 3 us off)
-        const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
-        if (sil_blocks + count_blocks > 0)
-            hipLaunchKernelGGL(k_silhouette_and_count, dim3(sil_blocks + count_blocks), dim3(256), 0, stream, fc,
-                               sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(), sc->d_faces.as<int32_t>(),
-                               fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap,
-                               fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                               fs->d_status.as<uint8_t>(), ctr, count_blocks);
+        // face set-up and silhouette search are independent: one launch
+        const unsigned setup_blocks = blocks_for(fc.n_faces, SETUP_BLOCK);
+        const unsigned sil_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, SETUP_BLOCK) : 0u;
+        if (setup_blocks + sil_blocks > 0)
+            hipLaunchKernelGGL(k_tri_setup, dim3(setup_blocks + sil_blocks), dim3(SETUP_BLOCK), 0, stream, fc,
+                               sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(),
+                               fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), fs->d_tris.as<TriRec>(),
+                               fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(),
+                               fs->d_valid.as<uint32_t>(), fs->d_count_list.as<uint32_t>(), ctr, ba, setup_blocks,
+                               sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(),
+                               fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap);
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
     if (shadows && fc.n_edges > 0) {
@@ -433,7 +435,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     // count of the large primitives' work items, scan, fill
     const unsigned list_blocks = blocks_for(std::max<long long>(fc.n_faces, n_tiles), 256);
     const unsigned large_blocks = 512;       // grid-stride over the work items, 4 wavefronts per block
-    hipLaunchKernelGGL(k_bin_large, dim3(large_blocks), dim3(256), 0, stream, fc, ba);
+    // one wavefront per face whose survivor count is still open, grid-stride; up to 512 workgroups: a mesh of
+    // large faces lists most of them (c2/c3: 128 -> 512 workgroups took 3 us off)
+    const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
+    hipLaunchKernelGGL(k_bin_large_and_count, dim3(count_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
+                       fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
+                       fs->d_status.as<uint8_t>(), ctr, count_blocks);
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[4], stream));
     hipLaunchKernelGGL(k_scan_bins, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, stream, fs->d_bin_count.as<uint32_t>(),
                        fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr,
