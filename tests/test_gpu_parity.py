@@ -262,3 +262,22 @@ def test_scene_changes_are_picked_up(api, oracle_mod):
     floor.textures.register("diffuse", __import__("os").path.join(scenes.ASSETS, "floor_diffuse.tga"), normalize=False)
     _against_oracle(api, oracle_mod, sc, label="after texture register")
     sc.close()
+
+
+@pytest.mark.parametrize("in_flight", [1, 4])
+def test_frames_in_flight_all_match(api, in_flight):
+    """bench.py's mode: successive frames enqueued on several HIP streams (mr_render_device), each
+    with its own work buffers inside the library.  Every frame that comes out must be the frame
+    a plain Scene.render() returns, whichever stream and slot produced it."""
+    import torch
+    from py_numpy_renderer_amd.multigpu import BandRenderer
+    scene = scenes.build(api, "diablo_floor_small")
+    want = scene.render()
+    br = BandRenderer(scene, 0, 1, shadows=True, light_timing=True, frames_in_flight=in_flight)
+    frames = [br.step() for _ in range(3 * in_flight)]
+    br.synchronize()
+    torch.cuda.synchronize()
+    for i, frame in enumerate(frames[-in_flight:]):
+        assert np.array_equal(frame.cpu().numpy(), want), f"frame of lane {i} differs"
+    scene._backend().stats()            # raises if a work list overflowed on any lane
+    scene.close()
