@@ -2,7 +2,7 @@
 //
 // Count -> scan -> fill, with the count folded into the kernels that create the primitives:
 //   k_tri_setup      every face that goes on to the visibility kernel adds itself to the
-//                    counts of the <= BIN_SMALL tiles it touches (bin_count_triangles); a face
+//                    counts of the <= BIN_SMALL tiles it touches (bin_triangles); a face
 //                    that spans more tiles is cut into work items of 64 tiles
 //   k_quad_setup     every shadow quad is cut into work items of 64 tiles
 //   k_bin_large_and_count   (kernels_geometry.h) count pass of the work items: one wavefront per
@@ -130,6 +130,12 @@ __device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArg
     }
     if (!want) mine = 0;
     const int my_leader = mine ? __ffsll((long long)mine) - 1 : lane;
+    if (!FILL) {
+        // the count pass does not need the old value: the atomic is issued without a return and the
+        // wavefront moves on (with the return it waited out a memory round trip per slot)
+        if (mine && lane == my_leader) atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mine));
+        return;
+    }
     uint32_t base = 0;
     if (mine && lane == my_leader) base = atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mine));
     base = (uint32_t)__shfl((int)base, my_leader);
