@@ -46,7 +46,8 @@ class Model(C.Structure):
                 ("materials", C.POINTER(Material)),
                 ("n_verts", C.c_int32), ("n_uv", C.c_int32), ("n_normals", C.c_int32),
                 ("n_faces", C.c_int32), ("n_materials", C.c_int32),
-                ("verts_f32", C.c_int32), ("clip", C.c_int32), ("depth_test", C.c_int32)]
+                ("verts_f32", C.c_int32), ("clip", C.c_int32), ("depth_test", C.c_int32),
+                ("edge_ids", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -134,7 +135,8 @@ def render_packed(packed, want_frame=True, want_status=True, want_silhouette=Tru
             mats[j].ns = pm.ns
             mats[j].tex_kd, mats[j].tex_norm, mats[j].tex_ks = pm.tex_kd, pm.tex_norm, pm.tex_ks
             mats[j].norm_tangent = int(pm.norm_tangent)
-        keep += [mats, m.vertices, m.uv, m.normals, m.faces]
+        keep += [mats, m.vertices, m.uv, m.normals, m.faces, m.edge_ids]
+        models[i].edge_ids = m.edge_ids.ctypes.data if m.edge_ids is not None else None
         models[i].verts = m.vertices.ctypes.data
         models[i].uv = m.uv.ctypes.data if m.uv is not None else None
         models[i].normals = m.normals.ctypes.data if m.normals is not None else None

@@ -336,7 +336,12 @@ static void fragment_normal(const ctx_t *c, const orc_texture *textures, const t
             for (int r = 0; r < 3; ++r)
                 raw[r] = chain3(T[r], B[r], n[r], (double)tx[0], (double)tx[1], (double)tx[2]);
         } else {
-            raw[0] = tx[0]; raw[1] = tx[1]; raw[2] = tx[2];
+            /* object-space map: the texel IS the normal, and normalize() (transformation.py:46-49)
+             * then runs on the float32 texels themselves: float32 squares, sum, sqrt and quotient */
+            float l = sqrtf((tx[0] * tx[0] + tx[1] * tx[1]) + tx[2] * tx[2]);
+            if (l == 0) l = 1;
+            for (int j = 0; j < 3; ++j) out[j] = (double)(tx[j] / l);
+            return;
         }
     } else if (m->normals) {
         raw[0] = interp[0]; raw[1] = interp[1]; raw[2] = interp[2];
@@ -778,7 +783,12 @@ int orc_render(const orc_frame *frame, const orc_model *models, int32_t n_models
                 double n[3];
                 face_normal_world(&t, n);
                 if (chain3(n[0], n[1], n[2], frame->light_pos[0], frame->light_pos[1], frame->light_pos[2]) > 0)
-                    for (int k = 0; k < 3; ++k) edge_toggle(&sets[mi], t.vi[k], t.vi[(k + 1) % 3], f * 3 + k);
+                    for (int k = 0; k < 3; ++k) {
+                        const int k2 = (k + 1) % 3;
+                        const int32_t ra = m->edge_ids ? m->edge_ids[(size_t)f * 3 + k] : t.vi[k];
+                        const int32_t rb = m->edge_ids ? m->edge_ids[(size_t)f * 3 + k2] : t.vi[k2];
+                        edge_toggle(&sets[mi], ra, rb, f * 3 + k);
+                    }
             }
             rasterize(&c, textures, m, f, gid, 0, o, &fb);
         }
@@ -797,7 +807,8 @@ int orc_render(const orc_frame *frame, const orc_model *models, int32_t n_models
                 o->silhouette[n_sil * 3 + 2] = e->b;
             }
             ++n_sil;
-            shadow_quad(&c, m, e->a, e->b, o);
+            /* model.vertices[e] (core.py:611): NumPy wraps negative indices */
+            shadow_quad(&c, m, e->a < 0 ? e->a + m->n_verts : e->a, e->b < 0 ? e->b + m->n_verts : e->b, o);
         }
         free(sets[mi].slots);
     }

@@ -82,6 +82,11 @@ typedef struct orc_model {
     int32_t verts_f32;         /* vertices were float32: edge vectors / silhouette normal use f32 arithmetic */
     int32_t clip;              /* Model.clip */
     int32_t depth_test;        /* Model.depth_test */
+    /* (n_faces, 3) vertex column of Model._faces exactly as the loader left it (negative = relative
+     * index, core.py:313), or NULL when it equals the vertex indices above.  The reference's Edge objects
+     * hash these raw values (triangular.py:286-302), so an edge written once as (3, 2) and once as
+     * (-7, -8) does not cancel although both name the same two vertices. */
+    const int32_t *edge_ids;
 } orc_model;
 
 typedef struct orc_stats {

@@ -36,6 +36,10 @@ class PackedModel:
     vertices_are_f32: bool
     clip: bool
     depth_test: bool
+    # (F, 3) int32: the vertex column of Model._faces as loaded (negative = relative).  The reference's
+    # silhouette set identifies an edge by these raw values (obj/triangular.py:286-302); None when they
+    # equal faces[..., 0]
+    edge_ids: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -177,11 +181,13 @@ def pack_model(model, textures, seen) -> PackedModel:
     out[..., 1] = _wrap(faces[..., 1].astype(np.int64), len(uv), "uv") if uv is not None else 0
     out[..., 2] = _wrap(faces[..., 2].astype(np.int64), len(normals), "normal") if normals is not None else 0
     out[..., 3] = _wrap(faces[..., 3].astype(np.int64), len(groups), "material group")
+    raw = faces[..., 0].astype(np.int64)
+    edge_ids = np.ascontiguousarray(raw, dtype=np.int32) if (raw < 0).any() else None
     return PackedModel(
         vertices=np.ascontiguousarray(verts, dtype=np.float64), uv=uv, normals=normals,
         faces=np.ascontiguousarray(out), materials=mats,
         vertices_are_f32=(verts.dtype == np.float32),
-        clip=bool(model.clip), depth_test=bool(model.depth_test))
+        clip=bool(model.clip), depth_test=bool(model.depth_test), edge_ids=edge_ids)
 
 
 def pack_scene(scene, shadows=True) -> PackedScene:

@@ -274,6 +274,7 @@ k_shade(const FrameConst fc, const ShadeArgs a)
         } else {
             // ---- Face.get_normals / tangent_ (obj/core.py:175-224)
             double raw[3], interp[3] = { 0, 0, 0 };
+            bool raw_is_unit = false;
             const bool has_n = (ff & FF_HAS_NORMALS) != 0;
             if (has_n) {
                 const float *n0 = a.normals + (size_t)ni[0] * 3, *n1 = a.normals + (size_t)ni[1] * 3,
@@ -316,7 +317,12 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                     for (int r = 0; r < 3; ++r)
                         raw[r] = chain3(T[r], Bt[r], n[r], (double)tx[0], (double)tx[1], (double)tx[2]);
                 } else {
-                    raw[0] = tx[0]; raw[1] = tx[1]; raw[2] = tx[2];
+                    // object-space map: the texel is the normal and normalize() runs on the float32
+                    // texels themselves (float32 squares, sum, sqrt, quotient; obj/transformation.py:46-49)
+                    float l = sqrtf((tx[0] * tx[0] + tx[1] * tx[1]) + tx[2] * tx[2]);
+                    if (l == 0) l = 1;
+                    raw[0] = (double)(tx[0] / l); raw[1] = (double)(tx[1] / l); raw[2] = (double)(tx[2] / l);
+                    raw_is_unit = true;
                 }
             } else if (has_n) {
                 raw[0] = interp[0]; raw[1] = interp[1]; raw[2] = interp[2];
@@ -341,7 +347,8 @@ k_shade(const FrameConst fc, const ShadeArgs a)
                 for (int j = 0; j < 3; ++j) raw[j] = chain3(p[0], p[1], p[2], fn[j], fn[j], fn[j]);
             }
             double N[3], L[3], V[3], Hh[3], tmp[3];
-            c_normalize3(raw, N);
+            if (raw_is_unit) { N[0] = raw[0]; N[1] = raw[1]; N[2] = raw[2]; }
+            else c_normalize3(raw, N);
 
             // ---- Blinn-Phong (obj/triangular.py:151-171)
             if (fc.light_type == MR_LIGHT_DIRECTIONAL) {

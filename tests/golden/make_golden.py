@@ -50,7 +50,8 @@ def import_reference():
     from obj.cube_map import CubeMap         # the class core.py's isinstance() test refers to (obj/core.py:8)
     api = types.SimpleNamespace(
         Model=core.Model, Camera=core.Camera, Light=core.Light, Scene=core.Scene, Lightning=Lightning, CubeMap=CubeMap,
-        SYSTEM=transformation.SYSTEM, SUBSYSTEM=transformation.SUBSYSTEM, scale=transformation.scale,
+        SYSTEM=transformation.SYSTEM, SUBSYSTEM=transformation.SUBSYSTEM,
+        PROJECTION_TYPE=transformation.PROJECTION_TYPE, scale=transformation.scale,
         translation=transformation.translation, rotate_xyz=transformation.rotate_xyz)
     return api, core, triangular
 
@@ -183,13 +184,76 @@ def save_full(name, r):
         json.dump(dict(counts=r.counts, stdout=r.stdout), fh, indent=1)
 
 
+def texture_digest(arr):
+    """What pins a loaded texture without storing it: shape, dtype, tangent flag, exact sum of the
+    float32 bit patterns and a few texels."""
+    arr = np.asarray(arr)
+    meta = arr.dtype.metadata or {}
+    flat = np.ascontiguousarray(arr).reshape(-1)
+    return dict(shape=list(arr.shape), dtype=arr.dtype.name, tangent=meta.get("tangent"),
+                bits_sum=int(flat.view(np.uint32).sum(dtype=np.uint64)) if arr.dtype == np.float32 else None,
+                probe=[float(v) for v in flat[:: max(1, flat.size // 7)][:8]])
+
+
+def material_record(mat):
+    """Every attribute the loader set on a Material (instance __dict__): scalars and small arrays by
+    value (with dtype), texture maps by digest."""
+    rec = {}
+    for key, val in sorted(vars(mat).items()):
+        if isinstance(val, np.ndarray) and val.ndim == 3:
+            rec[key] = dict(kind="texture", **texture_digest(val))
+        elif isinstance(val, np.ndarray):
+            rec[key] = dict(kind="array", dtype=val.dtype.name, value=[float(v) for v in val.ravel()])
+        else:
+            rec[key] = dict(kind=type(val).__name__, value=val)
+    return rec
+
+
+def loader_kat(api):
+    """Model.load_model / parse_mtl / TextureMaps.register of the reference on the synthetic files of
+    scenes.kat_files() and on cube.obj + cube.mtl (obj/core.py:72-105,257-348; obj/materials.py:57-77)."""
+    import scenes
+    files = dict(scenes.kat_files())
+    files["cube"] = os.path.join(scenes.ASSETS, "cube", "cube.obj")
+    arrays, meta = {}, {}
+    for key, path in files.items():
+        log = io.StringIO()
+        with contextlib.redirect_stdout(log):
+            m = api.Model.load_model(path)
+        for name in ("vertices", "uv", "normals", "_faces"):
+            val = getattr(m, name)
+            if val is not None:
+                arrays[f"{key}.{name}"] = np.asarray(val)
+        meta[key] = dict(
+            stdout=log.getvalue().replace(scenes.GENERATED, "<generated>"),
+            dtypes={n: (None if getattr(m, n) is None else np.asarray(getattr(m, n)).dtype.name)
+                    for n in ("vertices", "uv", "normals", "_faces")},
+            material_group=list(m.material_group),
+            materials={name: material_record(mat) for name, mat in m.materials.items()})
+    # TextureMaps.register: default normalize (x*2-1) with and without the tangent flag, and a colour map
+    m = api.Model.load_model(files["cube"])
+    tex = os.path.join(scenes.ASSETS, "floor_nm_tangent.tga")
+    m.textures.register("normals", tex, tangent=True)
+    m.textures.register("diffuse", os.path.join(scenes.ASSETS, "floor_diffuse.tga"), normalize=False)
+    m.textures.register("specular", tex)
+    meta["register"] = material_record(m.materials["default"])
+    np.savez_compressed(os.path.join(HERE, "loader_kat.npz"), **arrays)
+    with open(os.path.join(HERE, "loader_kat.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+    print("loader_kat:", {k: v.shape for k, v in arrays.items()}, flush=True)
+
+
 def main():
     import scenes
     ap = argparse.ArgumentParser()
     ap.add_argument("names", nargs="*")
     ap.add_argument("--full", action="store_true", help="also the 1080p BASELINE configs (minutes)")
+    ap.add_argument("--loader", action="store_true", help="only the loader known-answer fixture")
     args = ap.parse_args()
     api, core, triangular = import_reference()
+    if args.loader:
+        loader_kat(api)
+        return
     small = list(scenes.SMALL) + ["diablo_small_noshadow"] + list(scenes.OVERLAY)
     names = args.names or (small + (list(scenes.FULL) if args.full else []))
     for name in names:

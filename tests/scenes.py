@@ -27,7 +27,7 @@ def product_api():
     from py_numpy_renderer_amd import transformation as tr
     return SimpleNamespace(Model=pkg.Model, Camera=pkg.Camera, Light=pkg.Light, Scene=pkg.Scene,
                            Lightning=pkg.Lightning, SYSTEM=pkg.SYSTEM, SUBSYSTEM=pkg.SUBSYSTEM, CubeMap=pkg.CubeMap,
-                           scale=tr.scale, translation=tr.translation, rotate_xyz=tr.rotate_xyz)
+                           PROJECTION_TYPE=pkg.PROJECTION_TYPE, scale=tr.scale, translation=tr.translation, rotate_xyz=tr.rotate_xyz)
 
 
 # --------------------------------------------------------------------------- generated meshes
@@ -97,6 +97,51 @@ def bare_tetra_obj():
             "vt 0 0\nvt 1 0\nvt 0.5 1\n"
             "f 1/1/ 2/2/ 3/3/\nf 1/1/ 3/2/ 4/3/\nf 1/1/ 4/2/ 2/3/\nf 2/1/ 4/2/ 3/3/\n")
     return _write_if_changed(os.path.join(GENERATED, "bare_tetra.obj"), text)
+
+
+def kat_files():
+    """Synthetic OBJ/MTL pair for the loader known-answer test that is also
+    renderable: negative (relative) indices, quads and a 5-gon (fan triangulation), three
+    ``usemtl`` groups (one of them never defined in the library -> falls back to 'default'),
+    a fractional ``Ns``, ``map_Kd`` + ``map_bump`` (tangent-space ``norm``) and a texture file
+    that does not exist (the loader prints a hint and goes on).  The textures are copies of the
+    reference's floor textures, placed next to the library as ``.mtl`` paths are relative."""
+    import shutil
+    os.makedirs(GENERATED, exist_ok=True)
+    for src, dst in (("floor_diffuse.tga", "kat_diffuse.tga"), ("floor_nm_tangent.tga", "kat_bump.tga")):
+        if not os.path.exists(os.path.join(GENERATED, dst)):
+            shutil.copy(os.path.join(ASSETS, src), os.path.join(GENERATED, dst))
+    mtl = ("# loader known-answer library\n\n"
+           "newmtl brick\nNs 17.3\nKa 0.1 0.1 0.1\nKd 0.7 0.35 0.2\nKs 0.5 0.5 0.5\nd 1.0\nillum 2\n"
+           "map_Ks kat_missing.png\n\n"
+           "newmtl tiles\nNs 40\nKd 0.5 0.5 0.5\nKs 0.25 0.5 0.75\nmap_Kd kat_diffuse.tga\nmap_bump kat_bump.tga\n")
+    _write_if_changed(os.path.join(GENERATED, "kat.mtl"), mtl)
+    # a house: square base (quad, 'tiles'), four walls (quads, 'brick'), a pentagonal gable written with
+    # negative indices, and a roof triangle pair in a group the library does not define ('slate')
+    obj = ("mtllib kat.mtl\n"
+           "v -0.5 -0.4 -0.5\nv 0.5 -0.4 -0.5\nv 0.5 -0.4 0.5\nv -0.5 -0.4 0.5\n"
+           "v -0.5 0.3 -0.5\nv 0.5 0.3 -0.5\nv 0.5 0.3 0.5\nv -0.5 0.3 0.5\n"
+           "v 0 0.75 0.5 1.0\nv 0 0.75 -0.5\n"
+           "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 1.4 0.0\n"
+           "vn 0 -1 0\nvn 0 0 -1\nvn 1 0 0\nvn 0 0 1\nvn -1 0 0\nvn 0.7071 0.7071 0\nvn -0.7071 0.7071 0\n"
+           "usemtl tiles\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"
+           "usemtl brick\n"
+           "f 1/1/2 5/4/2 6/3/2 2/2/2\nf 2/1/3 6/4/3 7/3/3 3/2/3\nf 4/2/5 8/3/5 5/4/5 1/1/5\n"
+           "f -7/1/4 -8/2/4 -4/3/4 -2/5/4 -3/4/4\n"
+           "usemtl slate\n"
+           "f 6/1/6 10/4/6 9/3/6 7/2/6\nf -6/2/-1 -3/1/-1 -2/4/-1 -1/3/-1\n"
+           "usemtl brick\nf 5/1/2 10/5/2 6/2/2\n")
+    _write_if_changed(os.path.join(GENERATED, "kat.obj"), obj)
+    # no uv at all: v//vn corners (-1 in the uv column), with a quad and negative indices
+    nouv = ("v -0.3 -0.4 0.9\nv 0.3 -0.4 0.9\nv 0.3 0.1 0.9\nv -0.3 0.1 0.9\nv 0 0.1 1.3\n"
+            "vn 0 0 -1\nvn 0 1 0\nvn 0 0 1\n"
+            "f 1//1 4//1 3//1 2//1\nf -1//2 -3//2 -2//2\nf 1//3 2//3 5//3\n")
+    _write_if_changed(os.path.join(GENERATED, "kat_nouv.obj"), nouv)
+    # shapes the reference parses but cannot render: v/vt corners and bare v corners
+    _write_if_changed(os.path.join(GENERATED, "kat_v_vt.obj"),
+                      "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n")
+    _write_if_changed(os.path.join(GENERATED, "kat_v.obj"), "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 -1\n")
+    return {k: os.path.join(GENERATED, f"{k}.obj") for k in ("kat", "kat_nouv", "kat_v_vt", "kat_v")}
 
 
 # --------------------------------------------------------------------------- building blocks
@@ -239,6 +284,46 @@ def diablo_closeup(api, resolution=(200, 200)):
     return _scene(api, cam, dbg, _std_light(api), resolution, [_diablo(api)])
 
 
+def diablo_nm_object(api, resolution=(240, 320)):
+    """Object-space normal map (``register('normals', ..., tangent=False)``, obj/core.py:175-181):
+    the texel is the normal, no TBN."""
+    cam, dbg = _std_cameras(api)
+    d = os.path.join(ASSETS, "diablo3_pose")
+    m = api.Model.load_model(os.path.join(d, "diablo3_pose.obj"))
+    m.textures.register("normals", os.path.join(d, "diablo3_pose_nm.tga"), tangent=False)
+    m.textures.register("diffuse", os.path.join(d, "diablo3_pose_diffuse.tga"), normalize=False)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [m])
+
+
+def diablo_closeup_noclip(api, resolution=(200, 200)):
+    """``Model.clip = False`` (obj/triangular.py:80): the per-fragment frustum test is skipped, so
+    the fragments the close-up camera's planes would cut are kept."""
+    sc = diablo_closeup(api, resolution=resolution)
+    sc.models[0].clip = False
+    return sc
+
+
+def kat_house(api, resolution=(150, 200)):
+    """The loader known-answer meshes rendered: several material groups, fractional Ns
+    (``**`` takes the pow() path), map_bump from the library, a model without uv."""
+    files = kat_files()
+    cam, dbg = _std_cameras(api)
+    house = api.Model.load_model(files["kat"])
+    porch = api.Model.load_model(files["kat_nouv"])
+    return _scene(api, cam, dbg, _std_light(api, specular_strength=0.4), resolution, [house, porch, _floor(api)])
+
+
+def tetra_ortho(api, resolution=(120, 160)):
+    """Orthographic camera (obj/transformation.py:139-154; only OpenGL + LH exists upstream):
+    near = |position| (obj/core.py:389), float32 projection matrix."""
+    kw = dict(projection_type=api.PROJECTION_TYPE.ORTHOGRAPHIC, fovy=35, far=20, backface_culling=True)
+    cam = api.Camera((0.5, 1, 2), (0, 0, 0), **kw)
+    dbg = api.Camera((0.5, 1, 2), (0, 0, 0), **kw)
+    tet = api.Model.load_model(bare_tetra_obj())
+    return _scene(api, cam, dbg, _std_light(api), resolution, [tet, _floor(api)],
+                  system=api.SYSTEM.LH, subsystem=api.SUBSYSTEM.OPENGL)
+
+
 # name -> (builder, kwargs); the small ones have full golden buffers committed
 SMALL = {
     "cube_small": (cube_small, {}),
@@ -251,10 +336,15 @@ SMALL = {
     "diablo_closeup": (diablo_closeup, {}),
     "cube_skybox": (cube_skybox, {}),
     "torus_skybox_small": (torus_skybox, {"resolution": (216, 384), "nu": 60, "nv": 30}),
+    "diablo_nm_object": (diablo_nm_object, {}),
+    "diablo_closeup_noclip": (diablo_closeup_noclip, {}),
+    "kat_house": (kat_house, {}),
+    "tetra_ortho": (tetra_ortho, {}),
 }
 
 # BASELINE.json configs at full size: only the uint8 frame, winner map, stencil and z row sums are kept
 FULL = {
+    "c1_diablo_800x600": (diablo_small, {"resolution": (600, 800)}),       # BASELINE configs[0]; shadows off
     "c2_diablo_1080p": (diablo_small, {"resolution": (1080, 1920)}),       # rendered with shadows off
     "c3_diablo_floor_1080p": (diablo_floor, {"resolution": (1080, 1920)}),
     "c4_torus200k_1080p": (torus_floor, {"resolution": (1080, 1920), "nu": 500, "nv": 200}),
@@ -263,7 +353,7 @@ FULL = {
 HUGE = {
     "c5_torus1m_4k_skybox": (torus_skybox, {"resolution": (2160, 3840), "nu": 1000, "nv": 500}),
 }
-NO_SHADOW = {"c2_diablo_1080p", "diablo_small_noshadow"}
+NO_SHADOW = {"c1_diablo_800x600", "c2_diablo_1080p", "diablo_small_noshadow"}
 # the same scenes with upstream's debug-frustum overlay left on (obj/core.py:638)
 OVERLAY = ["diablo_small_overlay", "diablo_floor_lh_gl_overlay", "cube_outward_overlay"]
 
