@@ -1,24 +1,33 @@
 """bench.py -- Mfrag/s and frames/s of the rasterisation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[3], the scene the metric is quoted on; it fits one GPU):
-synthetic 200 000-triangle torus + floor, 1920x1080, point light, shadow volumes -- the scene
-recipe of SURVEY.md section 8(d) / BASELINE.md row c4, generated deterministically (no RNG).
+Workload (default c4 = BASELINE.json configs[3], the scene the metric is quoted on; it fits one
+GPU): synthetic 200 000-triangle torus + floor, 1920x1080, point light, shadow volumes -- the
+scene recipe of SURVEY.md section 8(d) / BASELINE.md row c4, generated deterministically (no RNG).
+``--config c5`` is BASELINE.json configs[4] (1M triangles + cubemap skybox at 3840x2160), c2 / c3
+the diablo configs.
 
-A step is one frame: vertex transform, triangle set-up, silhouette + shadow-quad set-up,
-binning, tile visibility (coverage, z, stencil), deferred shading and finalise to uint8, with
-the scene already resident in HBM and the frame left in HBM (``mr_render_device``).  With N > 1
-every rank renders a band of H/N output rows and ONE RCCL all-gather assembles the frame on
-every rank (fixed total work -> "strong" scaling).
+A frame is the whole hot path: per-frame constants in, vertex transform, face set-up, silhouette
++ shadow-quad set-up, binning, tile visibility (coverage, z, stencil), deferred shading and
+finalise to uint8, with the scene already resident in HBM and the frame left in HBM
+(``mr_render_device``).  A STEP is a batch of ``--frames-per-step`` (default 256) frames, so that the
+timed region is about half a second whatever --steps is; successive frames use DIFFERENT per-frame
+constants (the camera swings through 8 slightly different views), and ``--frames-in-flight``
+(default 4) of them are in flight on separate HIP streams.  With N > 1 every rank renders its share
+of the screen tiles (interleaved tile rows by default, ``--partition bands`` for contiguous row
+bands) and ONE RCCL all-gather assembles the frame on every rank (fixed total work -> "strong").
 
-value = reference-equivalent fragments per frame (2 x triangle fragments + shadow-quad
-fragments: the reference rasterises every triangle in two passes) / time.
+value = reference-equivalent fragments per frame (2 x triangle fragments + shadow-quad fragments:
+the reference rasterises every triangle in two passes) / time, summed over the views.
+The same line also carries the other regimes: one frame at a time (``latency_ms_single``,
+``value_single_frame``), with the fragment counters on (``value_counters_on``: no depth cull of
+shadow quads) and the host-visible ``Scene.render()`` (``scene_render_ms_host``: packing, per-frame
+upload, render, device->host copy into a NumPy array).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -34,9 +43,18 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
+N_VIEWS = 8
+
+CONFIGS = {
+    "c2": ("c2_diablo_1080p", "diablo3_pose (5 022 tris), 1920x1080, Phong + normal map, z-buffer only (BASELINE.json configs[1] / BASELINE.md c2)"),
+    "c3": ("c3_diablo_floor_1080p", "diablo3_pose + floor, 1920x1080, shadow volumes (BASELINE.json configs[2] / BASELINE.md c3)"),
+    "c4": ("c4_torus200k_1080p", "torus 500x200 (200k tris) + floor, 1920x1080, point light, shadow volumes (BASELINE.json configs[3] / BASELINE.md c4)"),
+    "c5": ("c5_torus1m_4k_skybox", "torus 1000x500 (1M tris) + floor + cubemap skybox, 3840x2160, shadow volumes (BASELINE.json configs[4] / BASELINE.md c5)"),
+}
+REFERENCE_MFRAGS = {"c2": 0.118, "c3": 0.609, "c4": 0.0239, "c5": 0.0224}     # BASELINE.md, reference NumPy loop, build container
 
 
-def algorithmic_bytes(st, npx, n_faces, textured_spec=False):
+def algorithmic_bytes(st, npx, n_faces, skybox=False, textured_spec=False):
     """Algorithmic HBM bytes of one frame in the reference's buffer formats:
     z float64, stencil int16, colour float32x3, texel float32x3.  Returned per kernel family
     and in total.  ``covered``/``lit`` pixel counts stand in for the reference's order-dependent
@@ -50,42 +68,67 @@ def algorithmic_bytes(st, npx, n_faces, textured_spec=False):
     visibility = visibility_tris + visibility_quads
     shading = ((12 + 12) * covered                   # pass 1: Kd texel + colour write
                + (12 + 12 + 12 + (4 if textured_spec else 0)) * lit   # pass 2: Kd + normal texel + write
-               + (12 + 15) * npx)                    # frame clear (12) + finalise read 12 / write 3
+               + (12 + 15) * npx                     # frame clear (12) + finalise read 12 / write 3
+               + ((24 + 12) * npx if skybox else 0))  # skybox fill: float64 texel + colour write per pixel
     primitives = 2 * (120 + 48) * n_faces + 32 * st["n_quads"]        # attributes + indices per pass
     return dict(visibility=visibility, visibility_tris=visibility_tris, visibility_quads=visibility_quads,
                 shading=shading, primitives=primitives,
                 total=visibility + shading + primitives)
 
 
-def cpu_baseline(scene, frags_per_frame, budget_s=12.0):
+def cpu_baseline(scene, frags_per_frame, label, budget_s=12.0):
     """The C oracle (oracle/, kind "port") on this host, one thread, same scene, bounded sample."""
     from oracle import oracle
     from py_numpy_renderer_amd._pack import pack_scene
     packed = pack_scene(scene, shadows=True)
-    oracle.render_packed(packed, want_status=False, want_silhouette=False)      # warm
+    sky = getattr(scene.skybox, "texels", None)
+    kw = dict(want_status=False, want_silhouette=False, sky_texels=sky)
+    t0 = time.perf_counter()
+    oracle.render_packed(packed, **kw)      # warm
+    one = time.perf_counter() - t0
     n, t0 = 0, time.perf_counter()
     while True:
-        oracle.render_packed(packed, want_status=False, want_silhouette=False)
+        oracle.render_packed(packed, **kw)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 40:
+        if dt + one > budget_s or n >= 40:
             break
     return {"value": round(frags_per_frame * n / dt / 1e6, 3), "unit": "Mfrag/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of the same 200k-triangle 1080p scene in {dt:.1f} s on 1 of "
+            "sample": f"{n} frames of the same scene ({label}) in {dt:.1f} s on 1 of "
                       f"{os.cpu_count()} host cores (oracle/raster_oracle.c; the reference's own NumPy loop "
-                      "measured 0.0239 Mfrag/s on this scene in the build container, BASELINE.md)",
+                      "measured the Mfrag/s in reference_numpy_mfrag_s on this scene in the build container, BASELINE.md)",
             "frames_per_s": round(n / dt, 3)}
+
+
+def swing_cameras(api, scene, n_views):
+    """*n_views* camera pairs on a short arc around the scene's camera (0.05 degrees apart about the
+    y axis): frames of a sequence differ in their per-frame constants, like these."""
+    import numpy as np
+    cam = scene.camera
+    kw = dict(fovy=cam.fovy, near=cam.near, far=cam.far, backface_culling=cam.backface_culling, up=cam.up,
+              projection_type=cam.projection_type)
+    base = np.asarray(cam.position, dtype=np.float64)
+    pairs = []
+    for k in range(n_views):
+        a = np.deg2rad((k - n_views // 2) * 0.05)
+        pos = (base[0] * np.cos(a) + base[2] * np.sin(a), base[1], -base[0] * np.sin(a) + base[2] * np.cos(a))
+        pairs.append((api.Camera(pos, cam.center, **kw), api.Camera(pos, cam.center, **kw)))
+    return pairs
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
+    ap.add_argument("--frames-per-step", type=int, default=256, help="frames in one step (a step is a batch of frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--all-marks", action="store_true", help="time every stage (9 event marks per frame instead of 5)")
+    ap.add_argument("--all-marks", action="store_true", help="time every stage (5 event marks per frame instead of 3)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="successive frames rendered on this many HIP streams (1 = one frame at a time)")
+    ap.add_argument("--partition", choices=("stripes", "bands"), default="stripes",
+                    help="screen-tile split for --gpus > 1: interleaved tile rows or contiguous row bands")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +139,7 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     import scenes
@@ -105,42 +149,79 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    H, W = 1080, 1920
+    scene_name, label = CONFIGS[args.config]
+    shadows = scene_name not in scenes.NO_SHADOW
     api = scenes.product_api()
-    scene = scenes.torus_floor(api, resolution=(H, W), nu=500, nv=200)
+    scene = scenes.build(api, scene_name)
+    H, W = (int(v) for v in scene.resolution)
     scene.device = local_rank
     backend = scene._backend()
     n_faces = sum(len(m._faces) for m in scene.models)
+    skybox = hasattr(scene.skybox, "texels")
+    base_cameras = (scene.camera, scene.debug_camera)
 
+    from py_numpy_renderer_amd._native import fill_frame_desc
+    from py_numpy_renderer_amd._pack import pack_frame
     from py_numpy_renderer_amd.multigpu import BandRenderer
 
-    # reference-equivalent fragment count of the WHOLE frame (one full render on this rank)
-    backend.render(scene, shadows=True)
-    full = dict(backend.last_stats)
-    frags_per_frame = 2 * full["frag_tri"] + full["frag_quad"]
-    frags_unique = full["frag_tri"] + full["frag_quad"]
+    partition = args.partition if world > 1 else "bands"
+    if partition == "bands" and H % world:
+        partition = "stripes"
 
-    br = BandRenderer(scene, rank, world, shadows=True, light_timing=not args.all_marks,
-                      frames_in_flight=args.frames_in_flight)
-    rows = br.band[1] - br.band[0]
-    step = br.step
-    # The counters of this rank's band, from one counted frame (MR_FRAME_COUNTERS).  The timed
-    # frames are rendered the way Scene.render() renders them, without the counters: like the
-    # reference, which counts nothing, they produce the frame only; it is checked below against
-    # a counted single-device frame.
-    backend.render(scene, shadows=True, row_band=br.band)
-    band_stats = dict(backend.last_stats)
+    def renderer(in_flight, light):
+        scene.camera, scene.debug_camera = base_cameras
+        return BandRenderer(scene, rank, world, shadows=shadows, light_timing=light,
+                            frames_in_flight=in_flight, partition=partition)
 
-    for _ in range(args.warmup):
-        step()
+    br = renderer(args.frames_in_flight, not args.all_marks)
+
+    # the views of the timed sequence: descriptors for this rank's tiles (timed frames: the frame only,
+    # like Scene.render()) and the reference-equivalent fragment counts of each whole frame
+    def descriptors(counters, light):
+        out = []
+        for cam, dbg in views:
+            scene.camera, scene.debug_camera = cam, dbg
+            out.append(fill_frame_desc(pack_frame(scene, shadows), br.band, light_timing=light, counters=counters,
+                                       stripe=br.stripe))
+        scene.camera, scene.debug_camera = base_cameras
+        return out
+
+    views = swing_cameras(api, scene, N_VIEWS)
+    frags_view, unique_view, stats_view = [], [], []
+    for cam, dbg in views:
+        scene.camera, scene.debug_camera = cam, dbg
+        backend.render(scene, shadows=shadows)                       # whole frame, counted
+        st = dict(backend.last_stats)
+        stats_view.append(st)
+        frags_view.append(2 * st["frag_tri"] + st["frag_quad"])
+        unique_view.append(st["frag_tri"] + st["frag_quad"])
+    scene.camera, scene.debug_camera = base_cameras
+    backend.render(scene, shadows=shadows)
+    full = dict(backend.last_stats)                                  # the base view = BASELINE.md's frame
+    frags_base = 2 * full["frag_tri"] + full["frag_quad"]
+    # this rank's share of the base view, counted (for the roofline's algorithmic bytes)
+    backend.render(scene, shadows=shadows, row_band=br.band if br.stripe is None else None, stripe=br.stripe)
+    part_stats = dict(backend.last_stats)
+    part_px = W * (br.band[1] - br.band[0]) if br.stripe is None else sum(
+        W * min(16, H - 16 * g) for g in range(-(-H // 16)) if g % world == rank)
+
+    br.set_descriptors(descriptors(False, not args.all_marks))
+    fps = max(1, args.frames_per_step)
+
+    def run(brx, n_frames):
+        for _ in range(n_frames):
+            brx.step()
+
+    run(br, args.warmup * fps)
+    if not br.verify():                  # a work list overflowed during warm-up: it has been grown, warm up again
+        run(br, args.warmup * fps)
+        assert br.verify(), "work lists kept overflowing"
     torch.cuda.synchronize()
-    backend.stats()                      # raises if a work list overflowed during warm-up (it is then grown)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(br, args.steps * fps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -150,75 +231,124 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    n_frames = args.steps * fps
+    assert br.verify(), "a work list overflowed in the timed frames"
+    ktimes, n_avg = backend.kernel_times(min(n_frames, 256))
+    last_frame = br.frame
 
-    backend.stats()                      # raises if a work list overflowed in the timed frames
-    ktimes, n_avg = backend.kernel_times(min(args.steps, 128))
+    # the frame every rank now holds must be the frame a single device renders for that view
+    view_of_last = (br.count - 1) % N_VIEWS
+    if rank == 0:
+        scene.camera, scene.debug_camera = views[view_of_last]
+        want = backend.render(scene, shadows=shadows)
+        scene.camera, scene.debug_camera = base_cameras
+        assert np.array_equal(last_frame.cpu().numpy(), want), "assembled frame differs from the single-device frame"
+    total_frags = sum(frags_view[i % N_VIEWS] for i in range(n_frames))
+    total_unique = sum(unique_view[i % N_VIEWS] for i in range(n_frames))
 
-    # The same frames again, one at a time and with every stage marked (outside the timed
-    # region): with several frames in flight a kernel shares the device with the other frames'
-    # kernels, so its duration above says how long it was resident, not how fast it runs.
-    solo = BandRenderer(scene, rank, world, shadows=True, light_timing=False, frames_in_flight=1)
-    for _ in range(40):
-        solo.step()
-    solo.synchronize()
-    ktimes_solo, n_solo = backend.kernel_times(32)
+    # ---- the other regimes, outside the timed region (fewer frames each)
+    def timed(brx, n):
+        run(brx, max(8, n // 8))
+        brx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run(brx, n)
+        brx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return (time.perf_counter() - t0) / n
+
+    n_side = max(64, min(n_frames // 4, 1024))
+    solo = renderer(1, False)                                        # one frame at a time, every stage marked
+    solo.set_descriptors(descriptors(False, False))
+    per_frame_solo = timed(solo, n_side)
+    ktimes_solo, _ = backend.kernel_times(min(n_side, 64))
+    counted = renderer(args.frames_in_flight, True)                  # fragment counters on: no depth cull of quads
+    counted.set_descriptors(descriptors(True, True))
+    per_frame_counted = timed(counted, n_side)
+
+    host_ms = None
+    if rank == 0 and world == 1:
+        scene.camera, scene.debug_camera = base_cameras
+        for _ in range(3):
+            scene.render(shadows=shadows)
+        samples = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            scene.render(shadows=shadows)
+            samples.append(time.perf_counter() - t0)
+        host_ms = float(np.median(samples) * 1e3)
 
     if rank == 0:
-        # the frame every rank now holds must be the frame a single device renders
-        import numpy as np
-        got = br.frame.cpu().numpy()
-        want = backend.render(scene, shadows=True)
-        assert np.array_equal(got, want), "assembled frame differs from the single-device frame"
-
-        ms = elapsed / args.steps * 1e3
-        alg = algorithmic_bytes(band_stats, W * rows, n_faces)
-        kernel_alg = {"tile_raster": alg["visibility_tris"], "tile_quads": alg["visibility_quads"], "shade": alg["shading"]}
-        dominant = max(kernel_alg, key=lambda k: ktimes[k])
-        k_ms = ktimes[dominant]
-        achieved = kernel_alg[dominant] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        per_frame = elapsed / n_frames
+        alg_full = algorithmic_bytes(full, W * H, n_faces, skybox)
+        alg = algorithmic_bytes(part_stats, part_px, n_faces, skybox)
+        # k_tile does the reference's three loops (coverage + z, stencil, shading + finalise); the
+        # per-primitive attribute reads belong to k_setup
+        tile_alg = alg["visibility"] + alg["shading"]
+        k_ms = ktimes["tile"]
+        achieved = tile_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(dominant)
+                traffic = json.load(fh).get(args.config, {}).get("k_tile")
+        mean_frags = total_frags / n_frames
         line = {
-            "metric": "Mfrag/s (1920x1080, 200k tris + shadow volumes)",
-            "value": round(frags_per_frame / (elapsed / args.steps) / 1e6, 2),
+            "metric": "Mfrag/s (1920x1080, 200k tris + shadow volumes)" if args.config == "c4"
+                      else f"Mfrag/s ({label.split(' (BASELINE')[0]})",
+            "value": round(total_frags / elapsed / 1e6, 2),
             "unit": "Mfrag/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4),
-            "frames_per_s": round(args.steps / elapsed, 2),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_frame": round(per_frame * 1e3, 5),
+            "frames_per_s": round(n_frames / elapsed, 2),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "torus 500x200 (200k tris) + floor, 1920x1080, point light, shadow volumes "
-                                   "(BASELINE.json configs[3] / BASELINE.md c4)",
-                       "fragments_per_frame": frags_per_frame, "unique_fragments_per_frame": frags_unique,
-                       "faces": n_faces, "frames_in_flight": args.frames_in_flight,
-                       "parallelism": f"screen row bands x{world}"
-                                                         + (" + 1 RCCL all-gather" if world > 1 else "")},
-            "mfrag_unique_per_s": round(frags_unique / (elapsed / args.steps) / 1e6, 2),
-            "gpu_ms_per_kernel": {k: round(v, 4) for k, v in ktimes.items()},
-            "frame_algorithmic_gb": round(alg["total"] / 1e9, 4),
-            "frame_hbm_frac": round(alg["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-            "frame_latency_ms": round(ktimes["frame"], 4),
-            "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 2),
+            "config": {"workload": label, "name": args.config, "frames_per_step": fps, "timed_frames": n_frames,
+                       "timed_seconds": round(elapsed, 4),
+                       "fragments_per_frame": frags_base, "fragments_per_frame_mean_over_views": round(mean_frags, 1),
+                       "unique_fragments_per_frame": full["frag_tri"] + full["frag_quad"],
+                       "faces": n_faces, "views": N_VIEWS, "frames_in_flight": args.frames_in_flight,
+                       "regime": "frames of a camera swing (8 views, 0.05 deg apart), per-frame constants new each frame, "
+                                 "frame left in HBM, fragment counters off",
+                       "parallelism": (f"screen tiles x{world} ({partition})" + (" + 1 RCCL all-gather" if world > 1 else ""))},
+            "mfrag_unique_per_s": round(total_unique / elapsed / 1e6, 2),
+            "latency_ms_single": round(per_frame_solo * 1e3, 5),
+            "latency_ms_single_device": round(ktimes_solo["frame"], 5),
+            "value_single_frame": round(mean_frags / per_frame_solo / 1e6, 2),
+            "value_counters_on": round(mean_frags / per_frame_counted / 1e6, 2),
+            "scene_render_ms_host": None if host_ms is None else round(host_ms, 4),
+            "value_scene_render_host": None if host_ms is None else round(frags_base / host_ms / 1e3, 2),
+            "reference_numpy_mfrag_s": REFERENCE_MFRAGS[args.config],
+            "gpu_ms_per_kernel": {k: round(v, 5) for k, v in ktimes.items()},
+            "gpu_ms_per_kernel_solo": {k: round(v, 5) for k, v in ktimes_solo.items()},
+            "frame_algorithmic_gb": round(alg_full["total"] / 1e9, 4),
+            "frame_hbm_frac": round(alg_full["total"] / per_frame / 1e9 / HBM_PEAK_GBS, 5),
+            "frame_hbm_frac_single": round(alg_full["total"] / per_frame_solo / 1e9 / HBM_PEAK_GBS, 5),
+            "roofline": {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": int(kernel_alg[dominant]),
-                         "avg_launch_ms": round(k_ms, 4), "launches_averaged": n_avg,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": int(tile_alg),
+                         "avg_launch_ms": round(k_ms, 5), "launches_averaged": n_avg,
                          "frames_in_flight": args.frames_in_flight,
-                         "note": "avg_launch_ms is the event span of the kernel in the timed region, where it shares the "
-                                 "device with the kernels of the other frames in flight; solo_* is the same kernel on the "
-                                 "same frames rendered one at a time right after the timed region",
-                         "solo_launch_ms": round(ktimes_solo[dominant], 4),
-                         "solo_achieved": round(kernel_alg[dominant] / (ktimes_solo[dominant] * 1e-3) / 1e9, 2),
-                         "solo_frac": round(kernel_alg[dominant] / (ktimes_solo[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "gpu_ms_per_kernel_solo": {k: round(v, 4) for k, v in ktimes_solo.items()},
+                         "note": "avg_launch_ms is the HIP-event span of k_tile in the timed region, where it shares the "
+                                 "device with the kernels of the other frames in flight; solo_* is the same kernel with one "
+                                 "frame at a time, right after the timed region.  The kernel's arithmetic is float64 on the "
+                                 "vector pipe (the reference's dtype); DESIGN.md section 5 has its VALU-side bound next to this one",
+                         "solo_launch_ms": round(ktimes_solo["tile"], 5),
+                         "solo_achieved": round(tile_alg / (ktimes_solo["tile"] * 1e-3) / 1e9, 2),
+                         "solo_frac": round(tile_alg / (ktimes_solo["tile"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene, frags_per_frame)
+            scene.camera, scene.debug_camera = base_cameras
+            line["cpu_baseline"] = cpu_baseline(scene, frags_base, args.config,
+                                                budget_s=25.0 if args.config == "c5" else 12.0)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 1
+#define MR_ABI_VERSION 2
 
 enum {
     MR_OK = 0,
@@ -47,13 +47,17 @@ enum {
     MR_FRAME_SHADOWS = 1,     /* run the shadow-volume stencil pass (obj/core.py:610-622) */
     MR_FRAME_KEEP_FLOAT = 2,  /* also keep the float32 frame (needed by mr_read_frame_f32) */
     MR_FRAME_FACE_STATUS = 4, /* also compute the per-face status histogram (obj/core.py:625-636) */
-    MR_FRAME_LIGHT_TIMING = 8, /* record only the event marks around the frame and the visibility kernels */
+    MR_FRAME_LIGHT_TIMING = 8, /* record only the event marks around the frame and the tile kernel */
     MR_FRAME_SKYBOX = 16,     /* fill the background from the cubemap of mr_scene_set_skybox (obj/core.py:595-596) */
-    MR_FRAME_COUNTERS = 32    /* keep the reference-equivalent fragment counters of mr_stats, and the reference's
+    MR_FRAME_COUNTERS = 32,   /* keep the reference-equivalent fragment counters of mr_stats, and the reference's
                                  stencil values at pixels no triangle covers (mr_read_stencil).  Without it only
                                  the frame is the contract and the library skips work that cannot change it
                                  (shadow quads that cannot pass the depth test anywhere in a strip of pixels);
                                  mr_render sets it by itself when it is handed a stats pointer. */
+    MR_FRAME_KEEP_BUFFERS = 64 /* also write the reference's working buffers (z_buffer, stencil_buffer, winner
+                                 face per pixel; obj/core.py:588-591) to device memory for mr_read_z /
+                                 mr_read_stencil / mr_read_winner.  Without it they only ever exist on chip,
+                                 tile by tile.  MR_FRAME_FACE_STATUS implies it. */
 };
 
 typedef struct mr_scene mr_scene;
@@ -68,7 +72,14 @@ typedef struct mr_frame_desc {
     int32_t light_type;             /* MR_LIGHT_* */
     int32_t flags;                  /* MR_FRAME_* */
     int32_t row_begin, row_end;     /* output rows [row_begin, row_end) this device renders;
-                                       0, height for the whole frame (screen-tile split) */
+                                       0, height for the whole frame (screen-tile split, contiguous bands) */
+    int32_t stripe_count, stripe_index;  /* screen-tile split, interleaved: with stripe_count = N > 1 this device
+                                       renders the tile rows (16 screen rows each, counted from the BOTTOM of the
+                                       frame like the reference's buffers) t with t mod N == stripe_index;
+                                       row_begin / row_end must then be 0 / height.  The output buffer holds
+                                       ceil(ceil(height / 16) / N) blocks of 16 x width x 3 bytes, this device's
+                                       highest tile row first, rows inside a block top-down (multigpu.py
+                                       un-permutes after the all-gather).  0 or 1 = off */
     double mvp[16];                 /* camera.MVP */
     double viewport[16];            /* camera.viewport */
     double debug_mvp[16];           /* debug_camera.MVP (obj/triangular.py:39) */
@@ -106,6 +117,11 @@ typedef struct mr_model_desc {
     const float *normals;           /* (n_normals, 3) Model.normals, or NULL */
     const int32_t *faces;           /* (n_faces, 3, 4) Model._faces: [vertex, uv, normal, material] per corner */
     const mr_material *materials;   /* (n_materials) indexed by the material column */
+    const int32_t *edge_ids;        /* (n_faces, 3) the vertex column of Model._faces exactly as the loader left it
+                                       (negative = relative index, obj/core.py:313), or NULL when it equals the
+                                       vertex indices in `faces`.  The reference's silhouette set hashes these raw
+                                       values (obj/triangular.py:286-302): an edge written once as (3, 2) and once
+                                       as (-7, -8) does not cancel although both name the same two vertices */
     int32_t n_vertices, n_uv, n_normals, n_faces, n_materials;
     int32_t vertices_are_f32;       /* Model.vertices.dtype == float32: edge vectors and the silhouette
                                        normal are then formed in float32 like NumPy does */
@@ -124,10 +140,9 @@ typedef struct mr_stats {
     int64_t n_quads, n_quads_drawn; /* silhouette edges / quads that reached rasterisation */
     int64_t tri_bin_entries, quad_bin_entries;   /* (primitive, tile) pairs */
     float gpu_ms_total;             /* device time of the whole frame (HIP events) */
-    float gpu_ms_geometry;          /* vertex transform + triangle set-up + silhouette + quad set-up */
-    float gpu_ms_binning;
-    float gpu_ms_raster;            /* tile visibility kernel (coverage, z, stencil) */
-    float gpu_ms_shade;             /* deferred shading + finalise */
+    float gpu_ms_setup;             /* k_setup: vertex transform, face set-up, silhouettes, shadow-quad set-up, own tile lists */
+    float gpu_ms_binning;           /* k_bin_work: tile lists of the large primitives, leftover survivor counts */
+    float gpu_ms_tile;              /* k_tile: coverage, z, stencil, shading, finalise */
     float gpu_ms_copy;              /* device -> host copy of the uint8 frame */
 } mr_stats;
 
@@ -164,6 +179,12 @@ int mr_scene_add_model(mr_scene *scene, const mr_model_desc *model);
 /* Drops all models and textures (keeps device allocations for reuse). */
 int mr_scene_clear(mr_scene *scene);
 
+/* Tuning / test hook: capacities of the per-frame work lists -- entries per 16x16 tile for the small
+ * triangle pairs, big triangle pairs and shadow quads, and entries of the large primitives' work list;
+ * 0 keeps the current value.  The lists grow by themselves (a frame that overflowed one is reported by
+ * mr_render / mr_get_stats as MR_E_OVERFLOW internally and rendered again); this only sets where they start. */
+int mr_scene_set_list_capacities(mr_scene *scene, uint32_t small_pairs, uint32_t big_pairs, uint32_t quads, uint32_t work);
+
 /* Scene.render() -- obj/core.py:587-640: depth/ambient pass, shadow-volume stencil pass, lit
  * pass and finalise (flip, **0.8, *255, uint8) on the GPU.  out_rgb receives
  * (row_end - row_begin) x width x 3 bytes, row 0 = top row of the band.  stats may be NULL. */
@@ -179,19 +200,18 @@ int mr_render_device(mr_scene *scene, const mr_frame_desc *frame, void *d_out_rg
 int mr_get_stats(mr_scene *scene, mr_stats *stats);
 
 /* Average device time in milliseconds (HIP events on the stream the kernels ran on) of each
- * stage over the last n_frames frames, most recent first; at most 128 are remembered.
- *   [0] vertex transform + light-facing flags     [1] face set-up (+ its bin counts) + silhouette search
- *   [2] shadow-quad set-up         [3] bin count of the work items + leftover survivor counts
- *   [4] binning, scan + fill passes
- *   [5] k_tile_raster              [6] k_tile_quads    [7] k_shade
- *   [8] whole frame (start -> after k_shade)
- * Frames rendered with MR_FRAME_LIGHT_TIMING report [0..4] as 0.
+ * stage over the last n_frames frames, most recent first; at most 64 per stream are remembered.
+ *   [0] k_vertex_mfma (0 unless MR_VERTEX_PATH=mfma)   [1] k_setup   [2] k_bin_work   [3] k_tile
+ *   [4] whole frame (start -> after k_tile)
+ * Frames rendered with MR_FRAME_LIGHT_TIMING report [0..1] as 0 and [2] as the span from the start of
+ * the frame to the start of k_tile.
  * Synchronises the device.  Returns the number of frames averaged or a negative error. */
-#define MR_N_KERNEL_TIMES 9
+#define MR_N_KERNEL_TIMES 5
 int mr_get_kernel_times(mr_scene *scene, int n_frames, float *out_ms, int cap);
 
 /* Debug taps for parity tests: the reference's working buffers after the last render
  * (obj/core.py:588-591).  Row = screen y (not flipped), as in the reference. */
+/* z, stencil and winner need a frame rendered with MR_FRAME_KEEP_BUFFERS. */
 int mr_read_z(mr_scene *scene, double *out_hw);            /* z_buffer, float64 (H, W) */
 int mr_read_stencil(mr_scene *scene, int16_t *out_hw);     /* stencil_buffer, int16 (H, W) */
 int mr_read_winner(mr_scene *scene, int32_t *out_hw);      /* face that owns each pixel, -1 = none */
@@ -202,11 +222,12 @@ int mr_read_face_status(mr_scene *scene, uint8_t *out_faces);  /* MR_FACE_* per 
  * (may exceed cap; only cap are written) or a negative error. */
 int mr_read_silhouette(mr_scene *scene, int32_t *out_triples, int32_t cap);
 
-/* Diagnostics: the visibility kernel's per-tile records of the last frame, 8 uint32 per tile:
- * [0..4] triangle fragments, quad fragments, stencil updates, covered px, lit px; [5],[6] start
- * and end of the tile's workgroup in 10 ns ticks (low 32 bits); [7] list sizes packed as
- * small | big << 12 | quads << 22.  Returns the number of tiles (tiles are 16 x 16 px, row-major
- * over the rendered band) or a negative error. */
+/* Diagnostics: the tile kernel's per-tile records of the last frame, MR_TILE_RECORD_WORDS uint32 per tile:
+ * [0..4] triangle fragments, quad fragments, stencil updates, covered px, lit px (MR_FRAME_COUNTERS);
+ * [5..7] lengths of the tile's lists: small triangle pairs, big triangle pairs, shadow quads;
+ * [8],[9] start and end of the tile's workgroup in 10 ns ticks (low 32 bits); [10],[11] reserved.
+ * Returns the number of tiles (tiles are 16 x 16 px, row-major over the rendered rows) or a negative error. */
+#define MR_TILE_RECORD_WORDS 12
 int mr_debug_read_tile_records(mr_scene *scene, uint32_t *out, int32_t cap_tiles);
 
 /* Human-readable description of the last error on this thread ("" if none). */

@@ -28,7 +28,9 @@ class Frame(C.Structure):
                 ("specular_strength", C.c_double), ("att_constant", C.c_double), ("att_linear", C.c_double),
                 ("att_quadratic", C.c_double), ("spot_edge0", C.c_double), ("spot_edge1", C.c_double),
                 ("background", C.c_float * 3), ("sky_size", C.c_int32), ("sky_texels", C.c_void_p),
-                ("sky_tri", C.c_int32 * 12), ("sky_rays", C.c_double * 18)]
+                ("sky_tri", C.c_int32 * 12), ("sky_rays", C.c_double * 18),
+                ("own_row_begin", C.c_int32), ("own_row_end", C.c_int32),
+                ("own_stripe_count", C.c_int32), ("own_stripe_index", C.c_int32)]
 
 
 class Texture(C.Structure):
@@ -93,11 +95,18 @@ def _fill(dst, src):
         dst[i] = v
 
 
-def render_packed(packed, want_frame=True, want_status=True, want_silhouette=True, sky_texels=None):
+def render_packed(packed, want_frame=True, want_status=True, want_silhouette=True, sky_texels=None,
+                  own_rows=None, own_stripe=None):
     """Run the oracle on a ``_pack.PackedScene``; returns a namespace of NumPy buffers.
-    *sky_texels*: uint8 (6, S, S, 3) cubemap when the frame carries skybox constants."""
+    *sky_texels*: uint8 (6, S, S, 3) cubemap when the frame carries skybox constants.
+    *own_rows* = (begin, end) output rows / *own_stripe* = (index, count) interleaved tile rows:
+    render only what one rank of the screen-tile split owns (the other rows keep their initial values)."""
     f = packed.frame
     fr = Frame()
+    if own_rows is not None:
+        fr.own_row_begin, fr.own_row_end = int(own_rows[0]), int(own_rows[1])
+    if own_stripe is not None:
+        fr.own_stripe_index, fr.own_stripe_count = int(own_stripe[0]), int(own_stripe[1])
     fr.width, fr.height, fr.system = f.width, f.height, f.system
     fr.backface_culling, fr.light_type = int(f.backface_culling), f.light_type
     fr.flags = FLAG_SHADOWS if f.shadows else 0

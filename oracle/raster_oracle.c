@@ -64,6 +64,19 @@ typedef struct {
     double two_nf, f_plus_n, f_minus_n;
 } ctx_t;
 
+/* Does the rank this frame is rendered for own screen row py (orc_frame.own_*)? */
+static inline int owned_row(const ctx_t *c, int py)
+{
+    const orc_frame *f = c->f;
+    if (f->own_row_end > f->own_row_begin) {
+        const int out_row = c->H - 1 - py;
+        if (out_row < f->own_row_begin || out_row >= f->own_row_end) return 0;
+    }
+    if (f->own_stripe_count > 1 && (py / 16) % f->own_stripe_count != f->own_stripe_index) return 0;
+    return 1;
+}
+
+
 /* core.py:226-228 Face.linearize_z; the same expression appears in triangular.py:352-354 */
 static inline double linearize(const ctx_t *c, double d)
 {
@@ -500,6 +513,7 @@ static int rasterize(const ctx_t *c, const orc_texture *textures, const orc_mode
     const int single_z = n == 1;
     size_t zpass = 0, keep = 0;
     for (size_t i = 0; i < n; ++i) {
+        if (!owned_row(c, fr[i].py)) continue;
         double z = rows_dot3(single_z, fr[i].b[0], fr[i].b[1], fr[i].b[2], t.zlin[0], t.zlin[1], t.zlin[2]);
         size_t at = (size_t)fr[i].py * W + fr[i].px;
         int pass = rh ? (o->z[at] >= z) : (o->z[at] <= z);
@@ -658,7 +672,7 @@ static void shadow_quad(const ctx_t *c, const orc_model *m, int32_t ea, int32_t 
                 double cr = ax * by - ay * bx;
                 in = is_front ? (cr > 0) : (cr < 0);
             }
-            if (!in) continue;
+            if (!in || !owned_row(c, py)) continue;
             o->stats.frag_quad += 1;
             double z = -((nx * (double)px + ny * (double)py) + Dp) / nz;
             z = linearize(c, z);

@@ -57,6 +57,11 @@ typedef struct orc_frame {
     const uint8_t *sky_texels;   /* (6, size, size, 3) uint8, CubeMap.textures * 255 */
     int32_t sky_tri[12];         /* the two triangles' screen vertices truncated to int, [t][v][xy] */
     double sky_rays[18];         /* their un-projected corner rays / w, [t][v][xyz] */
+    /* Screen-tile split (what one rank of the multi-GPU path owns; all 0 = the whole frame): output
+     * rows [own_row_begin, own_row_end) and, with own_stripe_count = N > 1, only the tile rows (16 screen
+     * rows, counted from the bottom) t with t mod N == own_stripe_index.  Fragments on rows the rank
+     * does not own are dropped; the buffers keep their initial values there. */
+    int32_t own_row_begin, own_row_end, own_stripe_count, own_stripe_index;
 } orc_frame;
 
 typedef struct orc_texture {

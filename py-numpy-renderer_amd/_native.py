@@ -19,12 +19,16 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 MR_OK = 0
 MR_E_OVERFLOW = -4
 FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SKYBOX, FRAME_COUNTERS = 1, 2, 4, 8, 16, 32
+FRAME_KEEP_BUFFERS = 64
+ABI_VERSION = 2
+TILE_RECORD_WORDS = 12
 
 
 class FrameDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("system", C.c_int32),
                 ("backface_culling", C.c_int32), ("light_type", C.c_int32), ("flags", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32),
+                ("stripe_count", C.c_int32), ("stripe_index", C.c_int32),
                 ("mvp", C.c_double * 16), ("viewport", C.c_double * 16), ("debug_mvp", C.c_double * 16),
                 ("frustum_planes", C.c_double * 24), ("z_near", C.c_double), ("z_far", C.c_double),
                 ("camera_pos", C.c_double * 3), ("light_pos", C.c_double * 3), ("light_dir", C.c_double * 3),
@@ -43,7 +47,7 @@ class MaterialDesc(C.Structure):
 
 class ModelDesc(C.Structure):
     _fields_ = [("vertices", C.c_void_p), ("uv", C.c_void_p), ("normals", C.c_void_p), ("faces", C.c_void_p),
-                ("materials", C.POINTER(MaterialDesc)),
+                ("materials", C.POINTER(MaterialDesc)), ("edge_ids", C.c_void_p),
                 ("n_vertices", C.c_int32), ("n_uv", C.c_int32), ("n_normals", C.c_int32),
                 ("n_faces", C.c_int32), ("n_materials", C.c_int32),
                 ("vertices_are_f32", C.c_int32), ("clip", C.c_int32), ("depth_test", C.c_int32)]
@@ -53,8 +57,7 @@ class Stats(C.Structure):
     _fields_ = ([(n, C.c_int64) for n in (
         "frag_tri", "frag_quad", "covered_px", "lit_px", "stencil_updates", "n_faces", "n_faces_setup",
         "n_quads", "n_quads_drawn", "tri_bin_entries", "quad_bin_entries")] +
-        [(n, C.c_float) for n in ("gpu_ms_total", "gpu_ms_geometry", "gpu_ms_binning", "gpu_ms_raster",
-                                  "gpu_ms_shade", "gpu_ms_copy")])
+        [(n, C.c_float) for n in ("gpu_ms_total", "gpu_ms_setup", "gpu_ms_binning", "gpu_ms_tile", "gpu_ms_copy")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -72,6 +75,7 @@ _PROTOTYPES = {
     "mr_scene_set_skybox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_scene_add_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
     "mr_scene_clear": (C.c_int, [C.c_void_p]),
+    "mr_scene_set_list_capacities": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "mr_render_device": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p]),
     "mr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
@@ -101,6 +105,8 @@ def load_library():
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.mr_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_NAME}: ABI version {lib.mr_abi_version()}, this binding speaks {ABI_VERSION}; rebuild")
         for which, struct in enumerate((FrameDesc, MaterialDesc, ModelDesc, Stats)):
             if lib.mr_abi_struct_size(which) != C.sizeof(struct):
                 raise RuntimeError(f"{LIB_NAME}: layout of {struct.__name__} differs from the binding "
@@ -116,14 +122,23 @@ def _check(rc, what):
     return rc
 
 
-def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False, counters=False):
+def stripe_out_rows(height, stripe_count):
+    """Rows of a device's output buffer in the striped layout (``mr_frame_desc.stripe_count``)."""
+    tile_rows = -(-int(height) // 16)
+    return -(-tile_rows // int(stripe_count)) * 16
+
+
+def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False, counters=False,
+                    keep_buffers=False, stripe=None):
     d = FrameDesc()
     d.width, d.height, d.system = pf.width, pf.height, pf.system
     d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
     d.flags = ((FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
                | (FRAME_LIGHT_TIMING if light_timing else 0) | (FRAME_FACE_STATUS if face_status else 0)
-               | (FRAME_COUNTERS if counters else 0))
+               | (FRAME_COUNTERS if counters else 0) | (FRAME_KEEP_BUFFERS if keep_buffers else 0))
     d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
+    if stripe is not None:                      # (index, count): interleaved tile rows, see mi355rast.h
+        d.stripe_index, d.stripe_count = int(stripe[0]), int(stripe[1])
     for name in ("mvp", "viewport", "debug_mvp", "frustum_planes", "camera_pos", "light_pos", "light_dir",
                  "light_color", "light_ambient"):
         dst = getattr(d, name)
@@ -192,6 +207,7 @@ class DeviceRenderer:
             d.normals = pm.normals.ctypes.data if pm.normals is not None else None
             d.faces = pm.faces.ctypes.data
             d.materials = mats
+            d.edge_ids = pm.edge_ids.ctypes.data if pm.edge_ids is not None else None
             d.n_vertices = len(pm.vertices)
             d.n_uv = 0 if pm.uv is None else len(pm.uv)
             d.n_normals = 0 if pm.normals is None else len(pm.normals)
@@ -213,20 +229,28 @@ class DeviceRenderer:
         self._sky_key = key
 
     # -- frames ---------------------------------------------------------------------------
-    def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False, counters=True):
-        """``mr_render``: returns the uint8 band ``(rows, W, 3)`` as a NumPy array.
+    def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False, counters=True,
+               keep_buffers=None, stripe=None):
+        """``mr_render``: returns the uint8 rows ``(rows, W, 3)`` as a NumPy array.
 
         ``counters=True`` (``MR_FRAME_COUNTERS``) also keeps the reference-equivalent fragment
-        counters in ``last_stats`` and the reference's stencil values at uncovered pixels --
-        what the parity tests and tools look at.  ``Scene.render`` passes ``False``: only the
-        frame is asked for, and shadow quads that cannot pass the depth test are skipped
-        (``last_stats`` then reports the fragment counters as -1)."""
+        counters in ``last_stats`` and the reference's stencil values at uncovered pixels;
+        ``keep_buffers`` (``MR_FRAME_KEEP_BUFFERS``, default: same as *counters*) also writes the
+        z-buffer / stencil / winner map to device memory for ``read_z`` and friends -- what the
+        parity tests and tools look at.  ``Scene.render`` passes ``False`` for both: only the
+        frame is asked for, those buffers never leave the chip, and shadow quads that cannot pass
+        the depth test are skipped (``last_stats`` then reports the fragment counters as -1).
+        ``stripe=(index, count)`` renders the interleaved tile rows of one device of a
+        multi-GPU split; the rows come back in the striped layout (``multigpu.unstripe``)."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status, counters=counters)
+        if keep_buffers is None:
+            keep_buffers = counters
+        desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status, counters=counters,
+                               keep_buffers=keep_buffers, stripe=stripe)
         self._n_faces = sum(len(m._faces) for m in scene.models)
-        rows = desc.row_end - desc.row_begin
+        rows = desc.row_end - desc.row_begin if stripe is None else stripe_out_rows(pf.height, stripe[1])
         out = np.empty((rows, pf.width, 3), dtype=np.uint8)
         stats = Stats()
         _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats) if counters else None),
@@ -238,12 +262,12 @@ class DeviceRenderer:
         return out
 
     def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False,
-                      counters=False):
+                      counters=False, stripe=None):
         """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters)
+        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters, stripe=stripe)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
         self._frame = (pf.height, pf.width)
@@ -255,19 +279,34 @@ class DeviceRenderer:
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
 
+    def set_list_capacities(self, small_pairs=0, big_pairs=0, quads=0, work=0):
+        """Where the per-tile work lists start (they grow on overflow); a tuning / test hook."""
+        _check(self.lib.mr_scene_set_list_capacities(self.handle, small_pairs, big_pairs, quads, work),
+               "mr_scene_set_list_capacities")
+
+    def overflowed(self):
+        """True when a frame enqueued with ``render_device`` overflowed a work list (the lists have then
+        been grown and the frame must be enqueued again); synchronises the device."""
+        st = Stats()
+        rc = self.lib.mr_get_stats(self.handle, C.byref(st))
+        if rc == MR_E_OVERFLOW:
+            return True
+        _check(rc, "mr_get_stats")
+        self.last_stats = st.as_dict()
+        return False
+
     def stats(self):
         st = Stats()
         _check(self.lib.mr_get_stats(self.handle, C.byref(st)), "mr_get_stats")
         self.last_stats = st.as_dict()
         return self.last_stats
 
-    KERNEL_TIME_NAMES = ("vertex+lit", "tri_setup+silhouette", "quad_setup", "bin_large+tri_count", "bin_scan_fill",
-                         "tile_raster", "tile_quads", "shade", "frame")
+    KERNEL_TIME_NAMES = ("vertex_mfma", "setup", "bin_work", "tile", "frame")
 
     def kernel_times(self, n_frames):
         """Average per-stage device milliseconds over the last *n_frames* frames (syncs)."""
-        buf = (C.c_float * 9)()
-        n = _check(self.lib.mr_get_kernel_times(self.handle, int(n_frames), buf, 9), "mr_get_kernel_times")
+        buf = (C.c_float * 5)()
+        n = _check(self.lib.mr_get_kernel_times(self.handle, int(n_frames), buf, 5), "mr_get_kernel_times")
         return dict(zip(self.KERNEL_TIME_NAMES, (float(v) for v in buf))), n
 
     # -- debug taps -----------------------------------------------------------------------
@@ -290,9 +329,10 @@ class DeviceRenderer:
         return self._tap(self.lib.mr_read_frame_f32, np.float32, (3,))
 
     def read_tile_records(self):
-        """Per-tile diagnostics of the visibility kernel: (n_tiles, 8) uint32, see mi355rast.h."""
-        n = _check(self.lib.mr_debug_read_tile_records(self.handle, (C.c_uint32 * 8)(), 0), "mr_debug_read_tile_records")
-        out = np.empty((max(n, 1), 8), dtype=np.uint32)
+        """Per-tile diagnostics of the tile kernel: (n_tiles, 12) uint32, see mi355rast.h."""
+        n = _check(self.lib.mr_debug_read_tile_records(self.handle, (C.c_uint32 * TILE_RECORD_WORDS)(), 0),
+                   "mr_debug_read_tile_records")
+        out = np.empty((max(n, 1), TILE_RECORD_WORDS), dtype=np.uint32)
         _check(self.lib.mr_debug_read_tile_records(self.handle, out.ctypes.data, n), "mr_debug_read_tile_records")
         return out[:n]
 

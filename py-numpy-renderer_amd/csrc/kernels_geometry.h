@@ -1,24 +1,32 @@
-// kernels_geometry.h -- per-vertex, per-face and per-silhouette-edge work of one frame.
+// kernels_geometry.h -- per-face and per-silhouette-edge work of one frame: everything that has
+// to exist before a tile can be rasterised, in TWO launches.
 //
-//   k_vertex      obj/triangular.py:36-45  (once per unique vertex instead of per face corner);
-//                 k_vertex_mfma does the same on the matrix cores (default), bit-identical
-//   k_tri_setup   obj/triangular.py:47-78, obj/core.py:127-136, obj/transformation.py:12-43
-//   k_tri_count   how many fragments of a face survive coverage + clip (decides NumPy's
-//                 dot-vs-gemv rounding of z, and the CLIPPED status)
-//   k_silhouette  obj/triangular.py:286-302 + obj/core.py:610-622 + obj/plane_intersection.py:59-86
-//                 + obj/triangular.py:320-340 (extrusion, clip, projection, plane, box)
+//   k_setup       face workgroups: vertex transform of the face's own corners
+//                 (obj/triangular.py:36-45), cull, pixel box, barycentric constants
+//                 (obj/triangular.py:47-78, obj/core.py:127-136, obj/transformation.py:12-43), the
+//                 shading attributes of the face (TriAttr), and the face's own tile lists;
+//                 edge workgroups: light-facing test from the static per-edge normals, silhouette
+//                 (obj/triangular.py:286-302), then extrusion, clip, projection, plane and box of
+//                 the shadow quad (obj/core.py:610-622, obj/plane_intersection.py:59-86,
+//                 obj/triangular.py:320-340)
+//   k_bin_work    the large primitives' tile lists (kernels_bin.h) and the survivor counts that
+//                 need a whole wavefront (how many fragments of a face survive coverage + clip
+//                 decides NumPy's dot-vs-gemv rounding of z, and the CLIPPED status)
+//   k_vertex_mfma the vertex transform once per unique vertex on the matrix cores, as a separate
+//                 launch in front of k_setup (MR_VERTEX_PATH=mfma; bit-identical)
+//   k_face_normals / k_edge_normals   static per scene: run when the scene is committed
 #pragma once
 
 #include "kernels_bin.h"
 
 namespace mr {
 
-// unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130),
-// dotted with light.position (obj/triangular.py:295)
-__device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *a, const double *b,
-                                            const double *c, bool verts_f32)
+// Unit normal of the world-space triangle in the vertices' own dtype (obj/core.py:127-130); the
+// light-facing test dots it with light.position (obj/triangular.py:295).  Static per face: computed
+// when the scene is committed.
+__device__ __forceinline__ void face_unit_normal(const double *a, const double *b, const double *c, bool verts_f32,
+                                                 double n[3])
 {
-    double n[3];
     if (verts_f32) {
         float e0[3], e1[3];
 #pragma unroll
@@ -40,48 +48,59 @@ __device__ __forceinline__ bool faces_light(const FrameConst &fc, const double *
                          e0[0] * e1[1] - e0[1] * e1[0] };
         normalize3(cr, n);
     }
-    return chain3(n[0], n[1], n[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0;
-}
-
-// Light-facing flag of every face (input of the silhouette search), thread per face.  It only
-// needs the static mesh and the light, so it rides along with the vertex transform as extra
-// workgroups of the frame's first launch instead of lengthening k_tri_setup.
-__device__ __forceinline__ void lit_body(const FrameConst &fc, const int32_t *__restrict__ faces,
-                                         const uint8_t *__restrict__ face_flags, const double *__restrict__ verts,
-                                         uint8_t *__restrict__ lit, uint32_t block)
-{
-    const int f = (int)(block * blockDim.x + threadIdx.x);
-    if (f >= fc.n_faces) return;
-    const int32_t *fcx = faces + (size_t)f * 12;
-    lit[f] = faces_light(fc, verts + (size_t)fcx[0] * 4, verts + (size_t)fcx[4] * 4, verts + (size_t)fcx[8] * 4,
-                         (face_flags[f] & FF_VERTS_F32) != 0) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256)
-k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
-         VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr, const int32_t *__restrict__ faces,
-         const uint8_t *__restrict__ face_flags, uint8_t *__restrict__ lit, uint32_t vertex_blocks)
+k_face_normals(int n_faces, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
+               const double *__restrict__ verts, double *__restrict__ face_n)
 {
-    if (blockIdx.x >= vertex_blocks) { lit_body(fc, faces, face_flags, verts, lit, blockIdx.x - vertex_blocks); return; }
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *ctr = Counters{};      // first kernel of the frame: every later one is stream-ordered after it
-    if (i >= fc.n_vertices) return;
-    double v[4] = { verts[i * 4 + 0], verts[i * 4 + 1], verts[i * 4 + 2], verts[i * 4 + 3] };
-    VertexOut o;
-    VertexClip oc;
+    const int f = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (f >= n_faces) return;
+    const int32_t *fcx = faces + (size_t)f * 12;
+    double n[3];
+    face_unit_normal(verts + (size_t)fcx[0] * 4, verts + (size_t)fcx[4] * 4, verts + (size_t)fcx[8] * 4,
+                     (face_flags[f] & FF_VERTS_F32) != 0, n);
+    face_n[(size_t)f * 4 + 0] = n[0]; face_n[(size_t)f * 4 + 1] = n[1]; face_n[(size_t)f * 4 + 2] = n[2];
+    face_n[(size_t)f * 4 + 3] = 0.0;
+}
+
+// Copies the incident faces' normals into the edge records (the host filled in the incidences).
+__global__ void __launch_bounds__(256)
+k_edge_normals(int n_edges, EdgeRec *__restrict__ edges, const double *__restrict__ face_n)
+{
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= n_edges) return;
+    EdgeRec r = edges[e];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.n[i][j] = r.inc[i] != 0xffffffffu ? face_n[(size_t)(r.inc[i] >> 2) * 4 + j] : 0.0;
+    edges[e] = r;
+}
+
+// One face corner through obj/triangular.py:36-45: clip = v @ MVP (and @ debug MVP), depth =
+// 1 / clip.w, ndc = clip * depth, screen = ndc @ viewport; plus linearize_z of the screen z.
+struct CornerOut {
+    double sx, sy, sz, depth, zlin;
+    double clip[4], clipd[4];
+    bool safe;
+};
+
+__device__ __forceinline__ void xform_vertex(const FrameConst &fc, const double v[4], CornerOut &o)
+{
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        oc.clip[j] = row_times_col(v, fc.mvp, j);
-        oc.clipd[j] = row_times_col(v, fc.debug_mvp, j);
+        o.clip[j] = row_times_col(v, fc.mvp, j);
+        o.clipd[j] = fc.same_clip ? o.clip[j] : row_times_col(v, fc.debug_mvp, j);
     }
-    double depth = 1.0 / oc.clip[3];
+    o.depth = 1.0 / o.clip[3];
     double ndc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ndc[j] = oc.clip[j] * depth;
+    for (int j = 0; j < 4; ++j) ndc[j] = o.clip[j] * o.depth;
     o.sx = row_times_col(ndc, fc.viewport, 0);
     o.sy = row_times_col(ndc, fc.viewport, 1);
     o.sz = row_times_col(ndc, fc.viewport, 2);
-    o.depth = depth;
     o.zlin = linearize_z(fc, o.sz);
     // Strictly inside both cameras' clip volumes with a relative margin of 1e-12.  A fragment's
     // clip coordinates are a non-negative combination of the corners' (weights u*dp/wc, all
@@ -89,35 +108,33 @@ k_vertex(const FrameConst fc, const double *__restrict__ verts, VertexOut *__res
     // when all three corners carry this flag the strict test of obj/triangular.py:85-87 cannot
     // fail for any fragment of the face and need not be evaluated.
     const double k = 1.0 - 1e-12;
-    const double wl = oc.clip[3] * k, wd = oc.clipd[3] * k;
-    o.safe = (fabs(oc.clip[0]) < wl && fabs(oc.clip[1]) < wl && fabs(oc.clip[2]) < wl &&
-              fabs(oc.clipd[0]) < wd && fabs(oc.clipd[1]) < wd && fabs(oc.clipd[2]) < wd) ? 1 : 0;
-    o.pad = 0;
-    out[i] = o;
-    out_clip[i] = oc;
+    const double wl = o.clip[3] * k, wd = o.clipd[3] * k;
+    o.safe = fabs(o.clip[0]) < wl && fabs(o.clip[1]) < wl && fabs(o.clip[2]) < wl &&
+             fabs(o.clipd[0]) < wd && fabs(o.clipd[1]) < wd && fabs(o.clipd[2]) < wd;
 }
 
-// The same vertex stage on the matrix cores.  The two products of obj/triangular.py:36-45
-// (v @ [MVP | debug MVP] and ndc @ viewport) are dense 16x4 by 4x16 contractions per 16
-// vertices, i.e. exactly one v_mfma_f64_16x16x4_f64 each.  Measured on MI355X
+// The vertex stage on the matrix cores, once per unique vertex.  The two products of
+// obj/triangular.py:36-45 (v @ [MVP | debug MVP] and ndc @ viewport) are dense 16x4 by 4x16
+// contractions per 16 vertices, i.e. exactly one v_mfma_f64_16x16x4_f64 each.  Measured on MI355X
 // (tools/micro/mfma_vertex_check.hip, 8.4 M outputs): that instruction accumulates k = 0..3 in
 // order with one rounding per step, bit-identical to the ascending fma chain the reference's
-// BLAS uses, so the result is the same VertexOut / VertexClip as k_vertex's, bit for bit.
+// BLAS uses, so the result is what xform_vertex computes, bit for bit.
 // One wavefront = 16 vertices.  Operand layout (cdna_hip_programming.md section 3): A lane l holds
 // A[row l%16][k l/16], B lane l holds B[k l/16][col l%16], D register i of lane l holds
 // D[row (l>>4) + 4i][col l&15]; the D -> A re-layout between the two products goes through LDS.
+// On CDNA4 the FP64 matrix rate equals the FP64 vector rate and half of the 16 output columns are
+// padding here, so this is a separate, optional launch (MR_VERTEX_PATH=mfma): by default every
+// face transforms its own three corners inside k_setup, which costs 3x the arithmetic and one
+// dependent launch less (DESIGN.md has both measured).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *__restrict__ out,
-              VertexClip *__restrict__ out_clip, Counters *__restrict__ ctr, const int32_t *__restrict__ faces,
-              const uint8_t *__restrict__ face_flags, uint8_t *__restrict__ lit, uint32_t vertex_blocks)
+              VertexClip *__restrict__ out_clip)
 {
-    if (blockIdx.x >= vertex_blocks) { lit_body(fc, faces, face_flags, verts, lit, blockIdx.x - vertex_blocks); return; }
     __shared__ double s_clip[4][16][8];     // per wavefront: [vertex][MVP x,y,z,w | debug x,y,z,w]
     __shared__ double s_scr[4][16][4];      // per wavefront: [vertex][screen x, y, z]
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr = Counters{};   // first kernel of the frame
     const int base = (blockIdx.x * (blockDim.x / WAVE) + wv) * 16;
     const int row = lane & 15, k = lane >> 4;
     const bool have = base + row < fc.n_vertices;
@@ -154,7 +171,7 @@ k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *
         o.sx = s_scr[wv][v][0]; o.sy = s_scr[wv][v][1]; o.sz = s_scr[wv][v][2];
         o.depth = 1.0 / oc.clip[3];
         o.zlin = linearize_z(fc, o.sz);
-        const double kk = 1.0 - 1e-12;                  // "safely inside" flag: see k_vertex
+        const double kk = 1.0 - 1e-12;                  // "safely inside" flag: see xform_vertex
         const double wl = oc.clip[3] * kk, wd = oc.clipd[3] * kk;
         o.safe = (fabs(oc.clip[0]) < wl && fabs(oc.clip[1]) < wl && fabs(oc.clip[2]) < wl &&
                   fabs(oc.clipd[0]) < wd && fabs(oc.clipd[1]) < wd && fabs(oc.clipd[2]) < wd) ? 1 : 0;
@@ -164,11 +181,9 @@ k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *
     }
 }
 
-// Survivors of coverage + clip among the first `limit` samples of a triangle's pixel box, as
-// seen by one lane walking the box sample by sample (stops at two).
-
-__device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const TriClip *clips,
-                                                int px, int py, bool &covered_in_band)
+// Survivors of coverage + clip among the samples of a triangle's pixel box, as seen by one lane.
+__device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const double dp[3],
+                                                const TriClip *clips, int px, int py, bool &covered_in_band)
 {
     const bool single = (t.flags & TF_SINGLE_BOX) != 0;
     float u, v, w;
@@ -178,7 +193,7 @@ __device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriR
     if (ok && (t.flags & TF_CLIP)) {
         const TriClip &c = clips[t.face];
         double p[3];
-        persp_bary(c.dp, u, v, w, single, p);
+        persp_bary(dp, u, v, w, single, p);
         ok = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
     }
     return ok;
@@ -187,9 +202,9 @@ __device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriR
 __device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, int f, uint32_t flags, int found)
 {
     if (found == 0) {
-        // The face was binned before this verdict (kernels_bin.h) and stays listed: the
-        // visibility kernel finds no surviving fragment for it and counts its covered ones
-        // (the fragment count is taken before the clip, obj/triangular.py:78).
+        // The face was binned before this verdict (kernels_bin.h) and stays listed: the tile
+        // kernel finds no surviving fragment for it and counts its covered ones (the fragment
+        // count is taken before the clip, obj/triangular.py:78).
         status[f] = FACE_CLIPPED;
     } else if (found == 1) {
         tris[f].flags = flags | TF_SINGLE_Z;
@@ -198,20 +213,52 @@ __device__ __forceinline__ void count_finish(TriRec *tris, uint8_t *status, int 
 
 constexpr int COUNT_SMALL_BOX = 32;   // pixel boxes up to this size are walked by a single lane
 
-// One face: status, TriRec / TriClip, light-facing flag.  Returns bit 0 = the face goes on to
-// the visibility kernel, bit 1 = its survivor count is left to k_tri_count; `covered` receives
-// the fragments of a face settled as CLIPPED right here.
-__device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const int32_t *__restrict__ faces,
-                                             const uint8_t *__restrict__ face_flags,
-                                             const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip,
-                                             TriRec *__restrict__ tris, TriClip *__restrict__ clips,
-                                             uint8_t *__restrict__ status, unsigned int &covered, PrimBox &pb, bool &clip)
-{
-    const int32_t *fcx = faces + (size_t)f * 12;
-    const int va = fcx[0], vb = fcx[4], vc = fcx[8];
-    const uint8_t ff = face_flags[f];
+struct SetupArgs {
+    const int32_t *faces;            // (F, 3, 4) global indices [vertex, uv, normal, material]
+    const uint8_t *face_flags;
+    const double *verts;             // (V, 4) world space
+    const float *uv, *normals;
+    const VertexOut *vout;           // PRE_XFORM only: what k_vertex_mfma left
+    const VertexClip *vclip;
+    TriRec *tris;
+    TriAttr *attrs;
+    TriClip *clips;
+    uint8_t *status;
+    uint32_t *count_list;            // faces whose survivor count needs a wavefront (k_bin_work)
+    Counters *ctr;
+    const EdgeRec *edges;            // static unique-edge table
+    const uint32_t *edge_inc;        // incidences beyond an edge's first two
+    const double *face_n;            // static face normals (for those)
+    int32_t *sil_edges;              // (quad_cap, 2): face, corner of each silhouette edge
+    QuadRec *quads;
+    uint32_t quad_cap;
+};
 
-    const VertexOut A = vout[va], B = vout[vb], C = vout[vc];
+// One face: status, TriRec / TriAttr / TriClip.  Returns bit 0 = the face goes on to the tile
+// kernel, bit 1 = its survivor count is left to k_bin_work; `covered` receives the fragments of a
+// face settled as CLIPPED right here.
+template <bool PRE_XFORM>
+__device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const SetupArgs &sa, unsigned int &covered,
+                                             PrimBox &pb, bool &clip)
+{
+    const int4 *row = reinterpret_cast<const int4 *>(sa.faces + (size_t)f * 12);
+    const int4 ia = row[0], ib = row[1], ic = row[2];          // [vertex, uv, normal, material] per corner
+    const uint8_t ff = sa.face_flags[f];
+    const double *wa = sa.verts + (size_t)ia.x * 4, *wb = sa.verts + (size_t)ib.x * 4, *wc = sa.verts + (size_t)ic.x * 4;
+
+    const double va[4] = { wa[0], wa[1], wa[2], wa[3] }, vb[4] = { wb[0], wb[1], wb[2], wb[3] },
+                 vc[4] = { wc[0], wc[1], wc[2], wc[3] };
+    CornerOut A, B, C;
+    if (PRE_XFORM) {
+        auto take = [&](int v, CornerOut &o) {
+            const VertexOut q = sa.vout[v];
+            o.sx = q.sx; o.sy = q.sy; o.sz = q.sz; o.depth = q.depth; o.zlin = q.zlin; o.safe = q.safe != 0;
+        };
+        take(ia.x, A); take(ib.x, B); take(ic.x, C);
+    } else {
+        xform_vertex(fc, va, A); xform_vertex(fc, vb, B); xform_vertex(fc, vc, C);
+    }
+    uint8_t *status = sa.status;
 
     // obj/triangular.py:47-48: z of the normalised screen-space normal
     if (fc.backface_culling) {
@@ -255,59 +302,80 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
     if (den == 0) { status[f] = FACE_EMPTY_B; return 0; }
     t.inv_den = 1.0f / den;
     t.zl0 = A.zlin; t.zl1 = B.zlin; t.zl2 = C.zlin;
-    t.pad[0] = t.pad[1] = 0;
+    t.material = ia.w;
+    t.pad = 0;
     long long box = (long long)(bx1 - bx0) * (long long)(by1 - by0);
     const bool need_clip = (ff & FF_CLIP) && !(A.safe && B.safe && C.safe);
     clip = need_clip;
-    t.flags = (need_clip ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u) | ((uint32_t)ff << 8);   // bits 8-15: face flags, for k_shade
+    t.flags = (need_clip ? TF_CLIP : 0u) | (box == 1 ? TF_SINGLE_BOX : 0u) | ((uint32_t)ff << 8);   // bits 8-15: face flags, for shading
     t.face = f;
     if (box <= 0) { status[f] = FACE_CLIPPED; return 0; }    // no sample inside the box
     status[f] = FACE_OK;
 
     // How many fragments survive coverage + clip (0 -> CLIPPED, 1 -> z is a dot, TF_SINGLE_Z)?
     // A small pixel box that needs no clip test is settled right here, by this lane, over the
-    // WHOLE frame (not just this device's band); the rest is left to k_tri_count.
+    // WHOLE frame (not just this device's band); the rest is left to k_bin_work.
     const bool count_here = !need_clip && box <= COUNT_SMALL_BOX;
+    const double dp[3] = { A.depth, B.depth, C.depth };
     if (count_here) {
         const int bw = bx1 - bx0;
         int found = 0;
         for (int idx = 0; idx < (int)box && found < 2; ++idx) {
             bool cov;
-            found += sample_survives(fc, t, nullptr, bx0 + idx % bw, by0 + idx / bw, cov) ? 1 : 0;
+            found += sample_survives(fc, t, dp, nullptr, bx0 + idx % bw, by0 + idx / bw, cov) ? 1 : 0;
             covered += cov ? 1u : 0u;
         }
         if (found == 0) {
-            status[f] = FACE_CLIPPED;              // never reaches the visibility kernel: its fragments are counted here
+            status[f] = FACE_CLIPPED;              // never reaches the tile kernel: its fragments are counted here
             return 0;
         }
         covered = 0;
         if (found == 1) t.flags |= TF_SINGLE_Z;
     }
-    tris[f] = t;
-    TriClip &cl = clips[f];
-    cl.dp[0] = A.depth; cl.dp[1] = B.depth; cl.dp[2] = C.depth;
-    if (need_clip) {
-        const VertexClip ca = vclip[va], cb = vclip[vb], cc = vclip[vc];
+    sa.tris[f] = t;
+
+    // shading attributes, gathered once per face (the corners' world positions are in registers)
+    TriAttr at;
+    at.dp[0] = dp[0]; at.dp[1] = dp[1]; at.dp[2] = dp[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cl.clip[0][j] = ca.clip[j]; cl.clip[1][j] = cb.clip[j]; cl.clip[2][j] = cc.clip[j];
-            cl.clipd[0][j] = ca.clipd[j]; cl.clipd[1][j] = cb.clipd[j]; cl.clipd[2][j] = cc.clipd[j];
+    for (int j = 0; j < 3; ++j) { at.world[0][j] = va[j]; at.world[1][j] = vb[j]; at.world[2][j] = vc[j]; }
+    const int ti[3] = { ia.y, ib.y, ic.y }, ni[3] = { ia.z, ib.z, ic.z };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (ff & FF_HAS_UV) { at.uv[k][0] = sa.uv[(size_t)ti[k] * 3]; at.uv[k][1] = sa.uv[(size_t)ti[k] * 3 + 1]; }
+        else at.uv[k][0] = at.uv[k][1] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) at.n[k][j] = (ff & FF_HAS_NORMALS) ? sa.normals[(size_t)ni[k] * 3 + j] : 0.f;
+    }
+    at.pad[0] = at.pad[1] = at.pad[2] = 0.f;
+    sa.attrs[f] = at;
+
+    if (need_clip) {
+        TriClip &cl = sa.clips[f];
+        if (PRE_XFORM) {
+            const VertexClip ca = sa.vclip[ia.x], cb = sa.vclip[ib.x], cc = sa.vclip[ic.x];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cl.clip[0][j] = ca.clip[j]; cl.clip[1][j] = cb.clip[j]; cl.clip[2][j] = cc.clip[j];
+                cl.clipd[0][j] = ca.clipd[j]; cl.clipd[1][j] = cb.clipd[j]; cl.clipd[2][j] = cc.clipd[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cl.clip[0][j] = A.clip[j]; cl.clip[1][j] = B.clip[j]; cl.clip[2][j] = C.clip[j];
+                cl.clipd[0][j] = A.clipd[j]; cl.clipd[1][j] = B.clipd[j]; cl.clipd[2][j] = C.clipd[j];
+            }
         }
     }
     return count_here ? 1 : 3;
 }
 
-constexpr int SETUP_BLOCK = 512;
+constexpr int SETUP_BLOCK = 256;
 
-// The two face lists (valid_list: faces to bin; count_list: faces k_tri_count still has to
-// settle) are appended to with ONE atomic per workgroup and list: the frame's counters share a
-// cache line, and same-line atomics retire at only ~0.3 per ns on MI355X
-// (tools/micro/atomic_bench.hip), so per-wavefront appends alone cost more than the set-up.
-__device__ __forceinline__ void
-tri_setup_block(const FrameConst &fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
-                const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris,
-                TriClip *__restrict__ clips, uint8_t *__restrict__ status, uint32_t *__restrict__ valid_list,
-                uint32_t *__restrict__ count_list, Counters *__restrict__ ctr, const BinArgs &bins, uint32_t block)
+// Face workgroup: one face per lane.  The list of faces whose survivor count needs a wavefront and
+// the frame's count of set-up faces are appended to with ONE atomic per workgroup.
+template <bool PRE_XFORM>
+__device__ __forceinline__ void tri_setup_block(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins, uint32_t block)
 {
     constexpr int NW = SETUP_BLOCK / WAVE;
     __shared__ uint32_t s_valid[NW], s_count[NW], s_covered;
@@ -317,10 +385,9 @@ tri_setup_block(const FrameConst &fc, const int32_t *__restrict__ faces, const u
     unsigned int covered = 0;
     PrimBox pb = { 0, 0, 0, 0 };
     bool clip = false;
-    const int r = f < fc.n_faces ? tri_setup_one(fc, f, faces, face_flags, vout, vclip, tris, clips, status, covered, pb, clip)
-                                 : 0;
-    // count pass of the binning for the faces that go on (kernels_bin.h)
-    bin_triangles<false>(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);
+    const int r = f < fc.n_faces ? tri_setup_one<PRE_XFORM>(fc, f, sa, covered, pb, clip) : 0;
+    // the face's own tile lists (kernels_bin.h)
+    bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);
     const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);
     if (lane == 0) { s_valid[wv] = (uint32_t)__popcll(bv); s_count[wv] = (uint32_t)__popcll(bc); }
     __syncthreads();
@@ -328,30 +395,29 @@ tri_setup_block(const FrameConst &fc, const int32_t *__restrict__ faces, const u
     if (threadIdx.x == 0) {
         uint32_t nv = 0, nc = 0;
         for (int w = 0; w < NW; ++w) { nv += s_valid[w]; nc += s_count[w]; }
-        uint32_t bvb = nv ? atomicAdd(&ctr->n_valid_tris, nv) : 0u;
-        uint32_t bcb = nc ? atomicAdd(&ctr->n_count, nc) : 0u;
+        if (nv) atomicAdd(&sa.ctr->n_valid_tris, nv);
+        uint32_t bcb = nc ? atomicAdd(&sa.ctr->n_count, nc) : 0u;
         for (int w = 0; w < NW; ++w) {
-            const uint32_t a = s_valid[w], b = s_count[w];
-            s_valid[w] = bvb; s_count[w] = bcb;
-            bvb += a; bcb += b;
+            const uint32_t b = s_count[w];
+            s_count[w] = bcb;
+            bcb += b;
         }
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (r & 1) valid_list[s_valid[wv] + (uint32_t)__popcll(bv & below)] = (uint32_t)f;
-    if (r & 2) count_list[s_count[wv] + (uint32_t)__popcll(bc & below)] = (uint32_t)f;
-    if (threadIdx.x == 0 && s_covered) atomicAdd(&ctr->frag_tri, (unsigned long long)s_covered);
+    if (r & 2) sa.count_list[s_count[wv] + (uint32_t)__popcll(bc & below)] = (uint32_t)f;
+    if (threadIdx.x == 0 && s_covered) atomicAdd(&sa.ctr->frag_tri, (unsigned long long)s_covered);
 }
 
-// Counts, per set-up triangle, the fragments that survive coverage + clip over the WHOLE frame
+// Counts, per listed face, the fragments that survive coverage + clip over the WHOLE frame
 // (not just this device's band), stopping as soon as two are found:
 //   0 -> the reference returns CLIPPED for the face; 1 -> z = bar @ zlin is a dot (TF_SINGLE_Z).
-// Only the faces k_tri_setup could not settle itself arrive here (pixel boxes over 32 samples,
+// Only the faces k_setup could not settle itself arrive here (pixel boxes over 32 samples,
 // or a per-fragment clip test).
 __device__ __forceinline__ void
 tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
-               const TriClip *__restrict__ clips, uint8_t *__restrict__ status, Counters *__restrict__ ctr,
-               uint32_t block, uint32_t n_blocks)
+               const TriAttr *__restrict__ attrs, const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
+               Counters *__restrict__ ctr, uint32_t block, uint32_t n_blocks)
 {
     // one wavefront per listed face, 64 samples per step, starting at the chunk that holds the
     // centroid (a well-shaped triangle is settled by that chunk alone)
@@ -361,6 +427,7 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
     for (uint32_t i = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; i < n_count; i += waves) {
         const int fb = (int)count_list[i];
         const TriRec tb = tris[fb];
+        const double dp[3] = { attrs[fb].dp[0], attrs[fb].dp[1], attrs[fb].dp[2] };
         const int w = tb.x1 - tb.x0;
         const long long n = (long long)w * (tb.y1 - tb.y0);
         const long long chunks = (n + WAVE - 1) / WAVE;
@@ -371,7 +438,7 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
         for (long long c = 0; c < chunks && found < 2; ++c) {
             const long long idx = ((first + c) % chunks) * WAVE + lane;
             bool cov = false, ok = false;
-            if (idx < n) ok = sample_survives(fc, tb, clips, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w), cov);
+            if (idx < n) ok = sample_survives(fc, tb, dp, clips, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w), cov);
             found += __popcll(__ballot(ok));
         }
         if (lane == 0) count_finish(tris, status, fb, tb.flags, found);
@@ -381,13 +448,14 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
 // Per-face result of the reference's lit pass (obj/triangular.py:101-112 with a stencil
 // buffer): a face that reached the depth stage is "rendered" when at least one of its fragments
 // has z <= the final z-buffer value (i.e. equals it) where stencil == 0, else EMPTY_Z.  Runs
-// after the visibility kernels, only when MR_FRAME_FACE_STATUS is set (obj/core.py:625-636
-// prints the histogram).  Same work split as k_tri_count; stops at the first such fragment.
-__device__ __forceinline__ bool sample_is_drawn(const FrameConst &fc, const TriRec &t, const TriClip *clips,
-                                                const double *zbuf, const int32_t *stencil, int px, int py)
+// after the tile kernel, only when MR_FRAME_FACE_STATUS is set (obj/core.py:625-636 prints the
+// histogram).  Thread per face; large boxes are walked by the whole wavefront.
+__device__ __forceinline__ bool sample_is_drawn(const FrameConst &fc, const TriRec &t, const double dp[3],
+                                                const TriClip *clips, const double *zbuf, const int32_t *stencil,
+                                                int px, int py)
 {
     bool cov;
-    if (!sample_survives(fc, t, clips, px, py, cov)) return false;
+    if (!sample_survives(fc, t, dp, clips, px, py, cov)) return false;
     float u, v, w;
     tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
     const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
@@ -397,23 +465,22 @@ __device__ __forceinline__ bool sample_is_drawn(const FrameConst &fc, const TriR
 }
 
 __global__ void __launch_bounds__(256)
-k_face_status(const FrameConst fc, const uint32_t *__restrict__ valid_list, const TriRec *__restrict__ tris,
+k_face_status(const FrameConst fc, const TriRec *__restrict__ tris, const TriAttr *__restrict__ attrs,
               const TriClip *__restrict__ clips, const double *__restrict__ zbuf, const int32_t *__restrict__ stencil,
-              uint8_t *__restrict__ status, const Counters *__restrict__ ctr)
+              uint8_t *__restrict__ status)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int lane = threadIdx.x & (WAVE - 1);
-    bool valid = i < ctr->n_valid_tris;
-    const int f = valid ? (int)valid_list[i] : 0;
-    valid = valid && status[f] == FACE_OK;
+    const bool valid = f < fc.n_faces && status[f] == FACE_OK;
     TriRec t = {};
-    if (valid) t = tris[f];
+    double dp[3] = { 0, 0, 0 };
+    if (valid) { t = tris[f]; dp[0] = attrs[f].dp[0]; dp[1] = attrs[f].dp[1]; dp[2] = attrs[f].dp[2]; }
     const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
     const int total = valid ? bw * bh : 0;
     if (valid && total <= COUNT_SMALL_BOX) {
         bool drawn = false;
         for (int idx = 0; idx < total && !drawn; ++idx)
-            drawn = sample_is_drawn(fc, t, clips, zbuf, stencil, t.x0 + idx % bw, t.y0 + idx / bw);
+            drawn = sample_is_drawn(fc, t, dp, clips, zbuf, stencil, t.x0 + idx % bw, t.y0 + idx / bw);
         if (!drawn) status[f] = FACE_EMPTY_Z;
     }
     unsigned long long big = __ballot(valid && total > COUNT_SMALL_BOX);
@@ -422,12 +489,13 @@ k_face_status(const FrameConst fc, const uint32_t *__restrict__ valid_list, cons
         big &= big - 1;
         const int fb = __shfl(f, src);
         const TriRec tb = tris[fb];
+        const double dpb[3] = { attrs[fb].dp[0], attrs[fb].dp[1], attrs[fb].dp[2] };
         const int w = tb.x1 - tb.x0;
         const long long n = (long long)w * (tb.y1 - tb.y0);
         bool any = false;
         for (long long base = 0; base < n && !any; base += WAVE) {
             const long long idx = base + lane;
-            const bool d = idx < n && sample_is_drawn(fc, tb, clips, zbuf, stencil, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w));
+            const bool d = idx < n && sample_is_drawn(fc, tb, dpb, clips, zbuf, stencil, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w));
             any = __ballot(d) != 0;
         }
         if (lane == 0 && !any) status[fb] = FACE_EMPTY_Z;
@@ -440,65 +508,9 @@ __device__ __forceinline__ double plane_dot(const double *P, const double *q)
     return chain4(P[0], P[1], P[2], P[3], q[0], q[1], q[2], q[3]);
 }
 
-// One thread per unique undirected edge of the scene.  An edge is on the silhouette when an
-// odd number of its incident light-facing faces toggled it; it keeps the orientation of the
-// last such face in face order (set add/discard semantics of obj/triangular.py:294-302).
-__device__ __forceinline__ void
-silhouette_body(const FrameConst &fc, const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
-                const int32_t *__restrict__ faces, const uint8_t *__restrict__ lit,
-                int32_t *__restrict__ sil_edges, uint32_t quad_cap, Counters *__restrict__ ctr, uint32_t block)
+__device__ __forceinline__ double shfl_d(double v, int src)
 {
-    int e = (int)(block * blockDim.x + threadIdx.x);
-    if (e >= fc.n_edges) return;
-    uint32_t cnt = 0, last = 0;
-    for (uint32_t k = edge_offset[e]; k < edge_offset[e + 1]; ++k) {
-        uint32_t inc = edge_inc[k];
-        if (lit[inc >> 2]) { ++cnt; last = inc; }
-    }
-    if (!(cnt & 1u)) return;
-    const int f = (int)(last >> 2), k = (int)(last & 3u), k2 = (k + 1) % 3;
-    const int ia = faces[(size_t)f * 12 + k * 4], ib = faces[(size_t)f * 12 + k2 * 4];
-
-    uint32_t sslot = atomicAdd(&ctr->n_quads, 1u);
-    if (sslot < quad_cap) {
-        sil_edges[sslot * 3 + 0] = f;        // the host maps the face back to its model
-        sil_edges[sslot * 3 + 1] = ia;
-        sil_edges[sslot * 3 + 2] = ib;
-    }
-}
-
-// The set-up of the faces and the silhouette search are independent (both read what the frame's
-// first launch wrote: screen-space vertices, light-facing flags), so they share a launch:
-// workgroups [0, setup_blocks) set faces up, the rest look for silhouette edges.  The leftover
-// survivor counts ride with the count pass of the large primitives' work items further down
-// the chain (nothing before the visibility kernel needs their verdict).  A nearly empty kernel
-// costs ~10 us of latency on its own, and under several frames in flight each stream spends a
-// third of its time between dependent kernels: every launch the chain loses is time gained.
-__global__ void __launch_bounds__(SETUP_BLOCK)
-k_tri_setup(const FrameConst fc, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
-            const VertexOut *__restrict__ vout, const VertexClip *__restrict__ vclip, TriRec *__restrict__ tris,
-            TriClip *__restrict__ clips, uint8_t *__restrict__ status, uint32_t *__restrict__ valid_list,
-            uint32_t *__restrict__ count_list, Counters *__restrict__ ctr, const BinArgs bins, uint32_t setup_blocks,
-            const uint32_t *__restrict__ edge_offset, const uint32_t *__restrict__ edge_inc,
-            const uint8_t *__restrict__ lit, int32_t *__restrict__ sil_edges, uint32_t quad_cap)
-{
-    if (blockIdx.x < setup_blocks)
-        tri_setup_block(fc, faces, face_flags, vout, vclip, tris, clips, status, valid_list, count_list, ctr, bins, blockIdx.x);
-    else
-        silhouette_body(fc, edge_offset, edge_inc, faces, lit, sil_edges, quad_cap, ctr, blockIdx.x - setup_blocks);
-}
-
-// Count pass of the work items (large faces, shadow quads) and the leftover survivor counts: the
-// few counting workgroups come first so that their latency-bound work is in flight early.
-__global__ void __launch_bounds__(256)
-k_bin_large_and_count(const FrameConst fc, const BinArgs bins, const uint32_t *__restrict__ count_list,
-                      TriRec *__restrict__ tris, const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
-                      Counters *__restrict__ ctr, uint32_t count_blocks)
-{
-    if (blockIdx.x < count_blocks)
-        tri_count_body(fc, count_list, tris, clips, status, ctr, blockIdx.x, count_blocks);
-    else
-        bin_large_body<false>(fc, bins, blockIdx.x - count_blocks, gridDim.x - count_blocks);
+    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
 }
 
 // Shadow-quad set-up: extrusion away from the light, Sutherland-Hodgman clipping against the
@@ -509,38 +521,28 @@ k_bin_large_and_count(const FrameConst fc, const BinArgs bins, const uint32_t *_
 // planes has at most ten).  A clipping step is then data-parallel: every lane tests its vertex
 // against the plane, fetches its successor with a lane shuffle, emits itself and/or the
 // intersection with the plane, and the emitted vertices are compacted (prefix sum of the emit
-// counts, through a few hundred bytes of LDS) back to one per lane.  A plane that keeps every
-// vertex is skipped (the walk would copy the polygon verbatim).  The arithmetic per vertex and
-// per edge is exactly the sequential algorithm's, so the quads are bit-identical; a thread
-// walking a scratch-resident polygon took 28 us for 1 133 quads, this takes a few.
+// counts, through a few hundred bytes of LDS private to the wavefront) back to one per lane.  A
+// plane that keeps every vertex is skipped (the walk would copy the polygon verbatim).  The
+// arithmetic per vertex and per edge is exactly the sequential algorithm's, so the quads are
+// bit-identical.  `have`: this 16-lane group has an edge (face, corner = sil_f, sil_k; list slot
+// s_idx).  Every lane of the wavefront must call it; s_poly is the wavefront's scratch.
 constexpr int QS_LANES = 16;
 static_assert(MAX_POLY <= QS_LANES, "one polygon vertex per lane");
 
-__device__ __forceinline__ double shfl_d(double v, int src)
+__device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins,
+                                                 bool have, int sil_f, int sil_k, uint32_t s_idx,
+                                                 double (*s_poly)[MAX_POLY + 4][4])
 {
-    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
-}
-
-__global__ void __launch_bounds__(64)
-k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const double *__restrict__ verts,
-             QuadRec *__restrict__ quads, uint32_t quad_cap, Counters *__restrict__ ctr, const BinArgs bins)
-{
-    __shared__ double s_poly[WAVE / QS_LANES][MAX_POLY + 4][4];
     const int lane = threadIdx.x & (WAVE - 1);
     const int grp = lane / QS_LANES, gl = lane % QS_LANES, g0 = grp * QS_LANES;
-    const uint32_t n_sil = min(ctr->n_quads, quad_cap);
-    constexpr uint32_t PER_BLOCK = WAVE / QS_LANES;
-    // fixed grid striding over the silhouette edges (their number is only known on the device)
-  for (uint32_t first = blockIdx.x * PER_BLOCK; first < n_sil; first += gridDim.x * PER_BLOCK) {
-    const uint32_t s_idx = first + grp;
-    const bool have = s_idx < n_sil;
 
     // ---- extrusion (obj/core.py:612-621): quad = (A, B, D, C); lanes 0..3 hold A, B, D, C
     double v[4] = { 0, 0, 0, 0 };
     int n = have ? 4 : 0;
     if (have && gl < 4) {
-        const int ia = sil_edges[s_idx * 3 + 1], ib = sil_edges[s_idx * 3 + 2];
-        const double *src = verts + (size_t)((gl == 0 || gl == 3) ? ia : ib) * 4;
+        const int32_t *fcx = sa.faces + (size_t)sil_f * 12;
+        const int ia = fcx[sil_k * 4], ib = fcx[((sil_k + 1) % 3) * 4];
+        const double *src = sa.verts + (size_t)((gl == 0 || gl == 3) ? ia : ib) * 4;
         for (int j = 0; j < 4; ++j) v[j] = src[j];
         if (gl >= 2) {
             if (fc.light_type == MR_LIGHT_POINT) {
@@ -591,17 +593,21 @@ k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const d
         }
         const int total = __shfl(incl, g0 + QS_LANES - 1);
         const bool clip_now = n > 0 && !all_in;
+        // the scratch is private to this wavefront and the LDS serves a wavefront's accesses in
+        // program order: a wave barrier (no code motion across it) is all the ordering it takes
+        __builtin_amdgcn_wave_barrier();
         if (clip_now) {
             int pos = incl - cnt;
             if (emit_cur && pos < MAX_POLY) { for (int j = 0; j < 4; ++j) s_poly[grp][pos][j] = v[j]; ++pos; }
             if (emit_int && pos < MAX_POLY) { for (int j = 0; j < 4; ++j) s_poly[grp][pos][j] = ipt[j]; }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (clip_now) {
             n = min(total, MAX_POLY);
             if (gl < n) for (int j = 0; j < 4; ++j) v[j] = s_poly[grp][gl][j];
         }
-        __syncthreads();
     }
     const bool alive = n >= 3;                           // obj/triangular.py:322-323
 
@@ -638,15 +644,15 @@ k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const d
     int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
     const bool boxed = alive && bound_box(xs, ys, 2, fc.width, fc.height, bx0, bx1, by0, by1);
     uint32_t slot = 0;
-    if (boxed && gl == 0) slot = atomicAdd(&ctr->n_quads_drawn, 1u);
+    if (boxed && gl == 0) slot = atomicAdd(&sa.ctr->n_quads_drawn, 1u);
     slot = (uint32_t)__shfl((int)slot, g0);
-    // count pass of the binning: the quad as work items of 64 tiles (kernels_bin.h); all lanes take part
+    // the quad as work items of 64 tiles (kernels_bin.h); all lanes take part
     push_work_items(bins, WORK_QUAD | slot,
-                    (boxed && gl == 0 && slot < quad_cap) ? quad_chunks(fc, bx0, bx1, by0, by1) : 0u);
-    if (!boxed) continue;
-    if (slot >= quad_cap) { if (gl == 0) atomicOr(&ctr->overflow, 4u); continue; }
+                    (boxed && gl == 0 && slot < sa.quad_cap) ? quad_chunks(fc, bx0, bx1, by0, by1) : 0u);
+    if (!boxed) return;
+    if (slot >= sa.quad_cap) { if (gl == 0) atomicOr(&sa.ctr->overflow, 16u); return; }
 
-    QuadRec &q = quads[slot];
+    QuadRec &q = sa.quads[slot];
     if (gl < MAX_POLY) {
         QuadEdge e;
         e.sx = used ? sx : 0.0; e.sy = used ? sy : 0.0;
@@ -666,7 +672,89 @@ k_quad_setup(const FrameConst fc, const int32_t *__restrict__ sil_edges, const d
         q.x0 = (int16_t)bx0; q.x1 = (int16_t)bx1; q.y0 = (int16_t)by0; q.y1 = (int16_t)by1;
         q.pad[0] = q.pad[1] = q.pad[2] = 0;
     }
-  }
+}
+
+// Edge workgroup: one unique undirected edge per lane.  An edge is on the silhouette when an odd
+// number of its incident light-facing faces toggled it; it keeps the orientation of the last
+// such face in face order (set add/discard semantics of obj/triangular.py:294-302).  The
+// incident faces' normals sit in the edge record, so the test is one 64-byte load and two dots.
+// The scene's edges are stored in a scrambled order (host, build_edge_table): the silhouette of a
+// mesh runs along consecutive vertex indices, and without that a wavefront would find dozens
+// of silhouette edges among its 64 and set their quads up four at a time while the rest of the
+// device idles.
+__device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins, uint32_t block)
+{
+    __shared__ double s_poly[SETUP_BLOCK / WAVE][WAVE / QS_LANES][MAX_POLY + 4][4];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    const int e = (int)(block * blockDim.x + threadIdx.x);
+    bool sil = false;
+    uint32_t last = 0;
+    if (e < fc.n_edges) {
+        const EdgeRec r = sa.edges[e];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (r.inc[i] != 0xffffffffu &&
+                chain3(r.n[i][0], r.n[i][1], r.n[i][2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0) {
+                ++cnt; last = r.inc[i];
+            }
+        }
+        for (uint32_t k = 0; k < r.extra_cnt; ++k) {
+            const uint32_t inc = sa.edge_inc[r.extra_off + k];
+            const double *fn = sa.face_n + (size_t)(inc >> 2) * 4;
+            if (chain3(fn[0], fn[1], fn[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0) { ++cnt; last = inc; }
+        }
+        sil = (cnt & 1u) != 0;
+    }
+    unsigned long long todo = __ballot(sil);
+    if (!todo) return;
+    // the wavefront's silhouette edges get consecutive list slots with one atomic
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&sa.ctr->n_quads, (uint32_t)__popcll(todo));
+    base = (uint32_t)__shfl((int)base, 0);
+    const uint32_t my_slot = base + (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
+    if (sil && my_slot < sa.quad_cap) {
+        sa.sil_edges[my_slot * 2 + 0] = (int32_t)(last >> 2);       // the host maps the face back to its model
+        sa.sil_edges[my_slot * 2 + 1] = (int32_t)(last & 3u);
+    }
+    // quad set-up, four silhouette edges per round (one per 16-lane group)
+    const int grp = lane / QS_LANES;
+    while (todo) {
+        int src = -1;
+        unsigned long long t = todo;
+        for (int g = 0; g <= grp && t; ++g) {                       // this group takes the grp-th set bit
+            const int b = __ffsll((long long)t) - 1;
+            t &= t - 1;
+            if (g == grp) src = b;
+        }
+        for (int g = 0; g < WAVE / QS_LANES && todo; ++g) todo &= todo - 1;
+        const bool have = src >= 0;
+        const uint32_t ls = (uint32_t)__shfl((int)last, have ? src : 0);
+        const uint32_t slot = (uint32_t)__shfl((int)my_slot, have ? src : 0);
+        quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap, (int)(ls >> 2), (int)(ls & 3u), slot, s_poly[wv]);
+    }
+}
+
+// First launch of the frame: workgroups [0, face_blocks) set faces up, the rest look at edges.
+template <bool PRE_XFORM>
+__global__ void __launch_bounds__(SETUP_BLOCK)
+k_setup(const FrameConst fc, const SetupArgs sa, const BinArgs bins, uint32_t face_blocks)
+{
+    if (blockIdx.x < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, blockIdx.x);
+    else edge_block(fc, sa, bins, blockIdx.x - face_blocks);
+}
+
+// Second launch: the leftover survivor counts (a few workgroups, first so that their
+// latency-bound work is in flight early) and the tile lists of the large primitives.
+__global__ void __launch_bounds__(256)
+k_bin_work(const FrameConst fc, const BinArgs bins, const uint32_t *__restrict__ count_list,
+           TriRec *__restrict__ tris, const TriAttr *__restrict__ attrs, const TriClip *__restrict__ clips,
+           uint8_t *__restrict__ status, Counters *__restrict__ ctr, uint32_t count_blocks)
+{
+    if (blockIdx.x < count_blocks)
+        tri_count_body(fc, count_list, tris, attrs, clips, status, ctr, blockIdx.x, count_blocks);
+    else
+        bin_work_body(fc, bins, blockIdx.x - count_blocks, gridDim.x - count_blocks);
 }
 
 }  // namespace mr

@@ -1,4 +1,4 @@
-// kernels_shade.h -- deferred shading and finalise, one thread per pixel.
+// kernels_shade.h -- deferred shading and finalise of one pixel (device functions of the tile kernel).
 //
 // The reference shades every z-passing fragment twice (ambient pass, then lit pass where
 // stencil == 0; obj/triangular.py:135-171) and converts the float frame at the end
@@ -14,29 +14,18 @@ namespace mr {
 
 struct ShadeArgs {
     const TriRec *tris;
-    const TriClip *clips;
-    const int32_t *faces;
-    const uint8_t *face_flags;
-    const double *verts;
-    const float *uv;
-    const float *normals;
+    const TriAttr *attrs;
     const Material *materials;
-    const Texture *textures;
-    const int32_t *winner;
-    const int32_t *stencil;    // 32-bit accumulator; the reference's buffer is its low 16 bits
     const uint8_t *sky;        // cubemap texels (6, S, S, 3) or null
     const float *gamma_lut;    // GAMMA_LUT_SIZE thresholds of the finalise step function
-    float *frame;          // optional float frame (row = screen y), may be null
-    uint8_t *out;          // band of the final frame, row 0 = top row of the band
+    float *frame;              // optional float frame (row = screen y), may be null
+    uint8_t *out;              // this device's rows of the final frame (see out_row)
 };
 
-// Face.get_UV (obj/core.py:138-143): nearest texel, truncation, Python negative-index wrap
-__device__ __forceinline__ const float *texel(const Texture &tx, const float *uv, const int ti[3],
-                                              const double p[3])
+// Face.get_UV (obj/core.py:138-143): nearest texel, truncation, Python negative-index wrap.
+// (tu, tv) = perspective barycentrics @ uv, computed once per pixel for all of the face's maps.
+__device__ __forceinline__ const float *texel(const Texture &tx, double tu, double tv)
 {
-    const double tu = gemv3(p[0], p[1], p[2], (double)uv[ti[0] * 3], (double)uv[ti[1] * 3], (double)uv[ti[2] * 3]);
-    const double tv = gemv3(p[0], p[1], p[2], (double)uv[ti[0] * 3 + 1], (double)uv[ti[1] * 3 + 1],
-                            (double)uv[ti[2] * 3 + 1]);
     const double cu = tu > 1.0 ? 1.0 : tu;
     double rv = 1.0 - tv;
     rv = rv > 1.0 ? 1.0 : rv;
@@ -206,198 +195,155 @@ __device__ __forceinline__ uint8_t gamma_u8(float x, const float *lut)
 
 __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v); }
 
-__global__ void __launch_bounds__(256, 2)
-k_shade(const FrameConst fc, const ShadeArgs a)
+// Colour of one covered pixel: the reference's two shading passes collapsed: the
+// pixel shows its winner face, lit (obj/triangular.py:149-171) where the stencil count is zero,
+// ambient only (obj/triangular.py:135-147) where it is not.  `mat` may live in LDS.
+__device__ __forceinline__ void shade_pixel(const FrameConst &fc, const TriRec &t, const TriAttr &at, const Material &mat,
+                                            int px, int py, bool lit, float rgb[3])
 {
-    // one workgroup per 16x16 pixel tile (the visibility kernel's tiles): neighbouring pixels
-    // share winners, so the gathers of records, attributes and texels stay in a few cache lines
-    __shared__ float s_gamma[GAMMA_LUT_SIZE];
-    s_gamma[threadIdx.x] = a.gamma_lut[threadIdx.x];
-    if (threadIdx.x == 0) s_gamma[GAMMA_LUT_SIZE - 1] = a.gamma_lut[GAMMA_LUT_SIZE - 1];
-    __syncthreads();
-    const int W = fc.width;
-    const int tile = (int)blockIdx.x;
-    const int px = (tile % fc.tiles_x) * TILE_W + ((int)threadIdx.x & (TILE_W - 1));
-    const int py = (tile / fc.tiles_x + fc.tile_y0) * TILE_H + (int)threadIdx.x / TILE_W;
-    if (px >= W || py < fc.band_y0 || py >= fc.band_y1) return;
-    const size_t at = (size_t)py * W + px;
+    const uint8_t ff = (uint8_t)(t.flags >> 8);
+    float u, v, w;
+    tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
+    double p[3];
+    persp_bary(at.dp, u, v, w, false, p);
+    const double tu = gemv3(p[0], p[1], p[2], (double)at.uv[0][0], (double)at.uv[1][0], (double)at.uv[2][0]);
+    const double tv = gemv3(p[0], p[1], p[2], (double)at.uv[0][1], (double)at.uv[1][1], (double)at.uv[2][1]);
 
-    float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
-    const int f = a.winner[at];
-    if (f < 0 && (fc.flags & MR_FRAME_SKYBOX) && a.sky) {
-        sky_color(fc, a.sky, px, py, rgb);
-    } else if (f < 0 && (fc.background_u8 >> 24)) {
-        // background: the host already finalised the colour with NumPy itself (obj/core.py:600,640)
-        if (a.frame) { a.frame[at * 3 + 0] = rgb[0]; a.frame[at * 3 + 1] = rgb[1]; a.frame[at * 3 + 2] = rgb[2]; }
-        uint8_t *o = a.out + ((size_t)(fc.band_y1 - 1 - py) * W + px) * 3;
-        o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
+    double color[3];
+    if (mat.map_kd.rgb) {
+        const float *tx = texel(mat.map_kd, tu, tv);
+        color[0] = tx[0]; color[1] = tx[1]; color[2] = tx[2];
+    } else {
+        color[0] = mat.kd[0]; color[1] = mat.kd[1]; color[2] = mat.kd[2];
+    }
+    const double *wa = at.world[0], *wb = at.world[1], *wc = at.world[2];
+    double pos[3], dl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        pos[j] = chain3(p[0], p[1], p[2], wa[j], wb[j], wc[j]);
+        dl[j] = fc.light_pos[j] - pos[j];
+    }
+    // Light.attenuation (obj/core.py:517-524)
+    const double dl2 = (dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2];
+    const double dist = dl2 > 0 ? dl2 * c_rsqrt(dl2) : 0.0;
+    const double att = c_rcp(fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
+
+    if (!lit) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rgb[j] = (float)clip01((att * fc.light_ambient[j]) * color[j]);
         return;
     }
-    if (f >= 0) {
-        const bool lit = (int16_t)a.stencil[at] == 0;
-        const TriRec t = a.tris[f];
-        const int32_t *fcx = a.faces + (size_t)f * 12;
-        const int vi[3] = { fcx[0], fcx[4], fcx[8] };
-        const int ti[3] = { fcx[1], fcx[5], fcx[9] };
-        const int ni[3] = { fcx[2], fcx[6], fcx[10] };
-        const Material &mat = a.materials[fcx[3]];
-        const uint8_t ff = a.face_flags[f];
-
-        float u, v, w;
-        tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
-        double p[3];
-        persp_bary(a.clips[f].dp, u, v, w, false, p);
-
-        double color[3];
-        if (mat.map_kd.rgb) {
-            const float *tx = texel(mat.map_kd, a.uv, ti, p);
-            color[0] = tx[0]; color[1] = tx[1]; color[2] = tx[2];
-        } else {
-            color[0] = mat.kd[0]; color[1] = mat.kd[1]; color[2] = mat.kd[2];
-        }
-        const double *wa = a.verts + (size_t)vi[0] * 4, *wb = a.verts + (size_t)vi[1] * 4,
-                     *wc = a.verts + (size_t)vi[2] * 4;
-        double pos[3], dl[3];
+    // ---- Face.get_normals / tangent_ (obj/core.py:175-224)
+    double raw[3], interp[3] = { 0, 0, 0 };
+    bool raw_is_unit = false;
+    const bool has_n = (ff & FF_HAS_NORMALS) != 0;
+    if (has_n) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            pos[j] = chain3(p[0], p[1], p[2], wa[j], wb[j], wc[j]);
-            dl[j] = fc.light_pos[j] - pos[j];
-        }
-        // Light.attenuation (obj/core.py:517-524)
-        const double dl2 = (dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2];
-        const double dist = dl2 > 0 ? dl2 * c_rsqrt(dl2) : 0.0;
-        const double att = c_rcp(fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
-
-        if (!lit) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) rgb[j] = (float)clip01((att * fc.light_ambient[j]) * color[j]);
-        } else {
-            // ---- Face.get_normals / tangent_ (obj/core.py:175-224)
-            double raw[3], interp[3] = { 0, 0, 0 };
-            bool raw_is_unit = false;
-            const bool has_n = (ff & FF_HAS_NORMALS) != 0;
-            if (has_n) {
-                const float *n0 = a.normals + (size_t)ni[0] * 3, *n1 = a.normals + (size_t)ni[1] * 3,
-                            *n2 = a.normals + (size_t)ni[2] * 3;
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    interp[j] = chain3(p[0], p[1], p[2], (double)n0[j], (double)n1[j], (double)n2[j]);
-            }
-            if (mat.map_norm.rgb) {
-                const float *tx = texel(mat.map_norm, a.uv, ti, p);
-                if (mat.norm_tangent) {
-                    double n[3], A[3][3], AI[3][3];
-                    c_normalize3(interp, n);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        if (ff & FF_VERTS_F32) {
-                            A[0][j] = (double)((float)wb[j] - (float)wa[j]);
-                            A[1][j] = (double)((float)wc[j] - (float)wa[j]);
-                        } else {
-                            A[0][j] = wb[j] - wa[j];
-                            A[1][j] = wc[j] - wa[j];
-                        }
-                        A[2][j] = n[j];
-                    }
-                    if (!inv3(A, AI))
-                        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) AI[i][j] = NAN;
-                    const float u0 = a.uv[ti[0] * 3], u1 = a.uv[ti[1] * 3], u2 = a.uv[ti[2] * 3];
-                    const float w0 = a.uv[ti[0] * 3 + 1], w1 = a.uv[ti[1] * 3 + 1], w2 = a.uv[ti[2] * 3 + 1];
-                    const double du[2] = { (double)(u1 - u0), (double)(u2 - u0) };
-                    const double dv[2] = { (double)(w1 - w0), (double)(w2 - w0) };
-                    double ti_[3], tj_[3], T[3], Bt[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        ti_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], du[0], du[1], 0.0);
-                        tj_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], dv[0], dv[1], 0.0);
-                    }
-                    c_normalize3(ti_, T);
-                    c_normalize3(tj_, Bt);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        raw[r] = chain3(T[r], Bt[r], n[r], (double)tx[0], (double)tx[1], (double)tx[2]);
-                } else {
-                    // object-space map: the texel is the normal and normalize() runs on the float32
-                    // texels themselves (float32 squares, sum, sqrt, quotient; obj/transformation.py:46-49)
-                    float l = sqrtf((tx[0] * tx[0] + tx[1] * tx[1]) + tx[2] * tx[2]);
-                    if (l == 0) l = 1;
-                    raw[0] = (double)(tx[0] / l); raw[1] = (double)(tx[1] / l); raw[2] = (double)(tx[2] / l);
-                    raw_is_unit = true;
-                }
-            } else if (has_n) {
-                raw[0] = interp[0]; raw[1] = interp[1]; raw[2] = interp[2];
-            } else {
-                // face normal (obj/core.py:127-130, 187), in the vertices' dtype
-                double fn[3];
-                if (ff & FF_VERTS_F32) {
-                    float e0[3], e1[3];
-                    for (int j = 0; j < 3; ++j) { e0[j] = (float)wb[j] - (float)wa[j]; e1[j] = (float)wc[j] - (float)wa[j]; }
-                    float cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
-                                    e0[0] * e1[1] - e0[1] * e1[0] };
-                    float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
-                    if (l == 0) l = 1;
-                    for (int j = 0; j < 3; ++j) fn[j] = (double)(cr[j] / l);
-                } else {
-                    double e0[3], e1[3];
-                    for (int j = 0; j < 3; ++j) { e0[j] = wb[j] - wa[j]; e1[j] = wc[j] - wa[j]; }
-                    double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
-                                     e0[0] * e1[1] - e0[1] * e1[0] };
-                    c_normalize3(cr, fn);
-                }
-                for (int j = 0; j < 3; ++j) raw[j] = chain3(p[0], p[1], p[2], fn[j], fn[j], fn[j]);
-            }
-            double N[3], L[3], V[3], Hh[3], tmp[3];
-            if (raw_is_unit) { N[0] = raw[0]; N[1] = raw[1]; N[2] = raw[2]; }
-            else c_normalize3(raw, N);
-
-            // ---- Blinn-Phong (obj/triangular.py:151-171)
-            if (fc.light_type == MR_LIGHT_DIRECTIONAL) {
-                L[0] = fc.light_dir[0]; L[1] = fc.light_dir[1]; L[2] = fc.light_dir[2];
-            } else {
-                c_normalize3(dl, L);
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) tmp[j] = fc.camera_pos[j] - pos[j];
-            c_normalize3(tmp, V);
-            if (fc.light_type == MR_LIGHT_SPOT) {
-                double x = (sum3(fc.light_dir, L) - fc.spot_edge0) * c_rcp(fc.spot_edge1 - fc.spot_edge0);
-                x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
-                const double in_light = x * x * (3 - 2 * x);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) color[j] = color[j] * in_light;
-            }
-            double spec_light[3];
-            if (mat.map_ks.rgb) {
-                const float *tx = texel(mat.map_ks, a.uv, ti, p);
-                const float s = tx[0] * 255.0f;               // float32 product (obj/core.py:149)
-                spec_light[0] = spec_light[1] = spec_light[2] = (double)s;
-            } else {
-                spec_light[0] = mat.ks255[0]; spec_light[1] = mat.ks255[1]; spec_light[2] = mat.ks255[2];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) tmp[j] = L[j] + V[j];
-            c_normalize3(tmp, Hh);
-            double nh = sum3(N, Hh);
-            nh = nh < 0 ? 0 : nh;
-            const double refl = np_power(nh, mat.ns);
-            const double nl = sum3(N, L);
+        for (int j = 0; j < 3; ++j)
+            interp[j] = chain3(p[0], p[1], p[2], (double)at.n[0][j], (double)at.n[1][j], (double)at.n[2][j]);
+    }
+    if (mat.map_norm.rgb) {
+        const float *tx = texel(mat.map_norm, tu, tv);
+        if (mat.norm_tangent) {
+            double n[3], A[3][3], AI[3][3];
+            c_normalize3(interp, n);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double spec = ((fc.light_color[j] * refl) * fc.specular_strength) * spec_light[j];
-                const double diff = nl * fc.light_color[j];
-                rgb[j] = (float)clip01((att * color[j]) * ((fc.light_ambient[j] + diff) + spec));
+                if (ff & FF_VERTS_F32) {
+                    A[0][j] = (double)((float)wb[j] - (float)wa[j]);
+                    A[1][j] = (double)((float)wc[j] - (float)wa[j]);
+                } else {
+                    A[0][j] = wb[j] - wa[j];
+                    A[1][j] = wc[j] - wa[j];
+                }
+                A[2][j] = n[j];
             }
-        }
-    }
-
-    if (a.frame) {
-        a.frame[at * 3 + 0] = rgb[0]; a.frame[at * 3 + 1] = rgb[1]; a.frame[at * 3 + 2] = rgb[2];
-    }
-    // finalise (obj/core.py:640): flip rows, ** 0.8, * 255, truncate
-    const int out_row = fc.band_y1 - 1 - py;
-    uint8_t *o = a.out + ((size_t)out_row * W + px) * 3;
+            if (!inv3(A, AI))
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) AI[i][j] = NAN;
+            const double du[2] = { (double)(at.uv[1][0] - at.uv[0][0]), (double)(at.uv[2][0] - at.uv[0][0]) };
+            const double dv[2] = { (double)(at.uv[1][1] - at.uv[0][1]), (double)(at.uv[2][1] - at.uv[0][1]) };
+            double ti_[3], tj_[3], T[3], Bt[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
+            for (int r = 0; r < 3; ++r) {
+                ti_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], du[0], du[1], 0.0);
+                tj_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], dv[0], dv[1], 0.0);
+            }
+            c_normalize3(ti_, T);
+            c_normalize3(tj_, Bt);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                raw[r] = chain3(T[r], Bt[r], n[r], (double)tx[0], (double)tx[1], (double)tx[2]);
+        } else {
+            // object-space map: the texel is the normal and normalize() runs on the float32
+            // texels themselves (float32 squares, sum, sqrt, quotient; obj/transformation.py:46-49)
+            float l = sqrtf((tx[0] * tx[0] + tx[1] * tx[1]) + tx[2] * tx[2]);
+            if (l == 0) l = 1;
+            raw[0] = (double)(tx[0] / l); raw[1] = (double)(tx[1] / l); raw[2] = (double)(tx[2] / l);
+            raw_is_unit = true;
+        }
+    } else if (has_n) {
+        raw[0] = interp[0]; raw[1] = interp[1]; raw[2] = interp[2];
+    } else {
+        // face normal (obj/core.py:127-130, 187), in the vertices' dtype
+        double fn[3];
+        if (ff & FF_VERTS_F32) {
+            float e0[3], e1[3];
+            for (int j = 0; j < 3; ++j) { e0[j] = (float)wb[j] - (float)wa[j]; e1[j] = (float)wc[j] - (float)wa[j]; }
+            float cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                            e0[0] * e1[1] - e0[1] * e1[0] };
+            float l = sqrtf((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+            if (l == 0) l = 1;
+            for (int j = 0; j < 3; ++j) fn[j] = (double)(cr[j] / l);
+        } else {
+            double e0[3], e1[3];
+            for (int j = 0; j < 3; ++j) { e0[j] = wb[j] - wa[j]; e1[j] = wc[j] - wa[j]; }
+            double cr[3] = { e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2],
+                             e0[0] * e1[1] - e0[1] * e1[0] };
+            c_normalize3(cr, fn);
+        }
+        for (int j = 0; j < 3; ++j) raw[j] = chain3(p[0], p[1], p[2], fn[j], fn[j], fn[j]);
+    }
+    double N[3], L[3], V[3], Hh[3], tmp[3];
+    if (raw_is_unit) { N[0] = raw[0]; N[1] = raw[1]; N[2] = raw[2]; }
+    else c_normalize3(raw, N);
+
+    // ---- Blinn-Phong (obj/triangular.py:151-171)
+    if (fc.light_type == MR_LIGHT_DIRECTIONAL) {
+        L[0] = fc.light_dir[0]; L[1] = fc.light_dir[1]; L[2] = fc.light_dir[2];
+    } else {
+        c_normalize3(dl, L);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tmp[j] = fc.camera_pos[j] - pos[j];
+    c_normalize3(tmp, V);
+    if (fc.light_type == MR_LIGHT_SPOT) {
+        double x = (sum3(fc.light_dir, L) - fc.spot_edge0) * c_rcp(fc.spot_edge1 - fc.spot_edge0);
+        x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+        const double in_light = x * x * (3 - 2 * x);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) color[j] = color[j] * in_light;
+    }
+    double spec_light[3];
+    if (mat.map_ks.rgb) {
+        const float *tx = texel(mat.map_ks, tu, tv);
+        const float s = tx[0] * 255.0f;               // float32 product (obj/core.py:149)
+        spec_light[0] = spec_light[1] = spec_light[2] = (double)s;
+    } else {
+        spec_light[0] = mat.ks255[0]; spec_light[1] = mat.ks255[1]; spec_light[2] = mat.ks255[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tmp[j] = L[j] + V[j];
+    c_normalize3(tmp, Hh);
+    double nh = sum3(N, Hh);
+    nh = nh < 0 ? 0 : nh;
+    const double refl = np_power(nh, mat.ns);
+    const double nl = sum3(N, L);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double spec = ((fc.light_color[j] * refl) * fc.specular_strength) * spec_light[j];
+        const double diff = nl * fc.light_color[j];
+        rgb[j] = (float)clip01((att * color[j]) * ((fc.light_ambient[j] + diff) + spec));
+    }
 }
 
 }  // namespace mr

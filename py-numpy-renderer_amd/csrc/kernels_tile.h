@@ -1,0 +1,562 @@
+// kernels_tile.h -- the tile kernel: everything between the tile lists and the finished pixels.
+//
+// Design (MI355X-first, not a port of the reference's per-face loops): the frame is cut into
+// 16x16-pixel tiles; one 256-thread workgroup owns one tile from the first triangle to the uint8
+// pixels.  The tile's z-buffer and winner map live in LDS, each pixel's stencil count in a
+// register of the thread that owns the pixel, so the frame's z / stencil / float colour -- the
+// buffers the reference's three loops hammer (obj/core.py:588-591) -- never exist in HBM unless a
+// caller asks to read them back.  Measured on MI355X (tools/micro/atomic_bench.hip): scattered
+// 64-bit global atomics run at 24 G/s, LDS atomics at 1 900 G/s.
+//
+// Phases of a tile (k_tile):
+//   1. big (triangle, tile) pairs -- a floor triangle -- one PIXEL per thread, the records staged
+//      64 at a time in registers and broadcast with v_readlane (obj/triangular.py:72-118);
+//   2. small pairs -- a dense mesh's triangles cover a handful of samples -- four lanes per
+//      TRIANGLE: they share out the few samples of the pixel box and do an LDS atomicMin on the
+//      order-preserving key of z, then (second sweep) an LDS atomicMax of the face index where its
+//      z is the tile's final z.  The reference's sequential rule (a fragment writes when
+//      zbuf >= z, so the last face in order wins ties) is reproduced order-free: smallest z, and
+//      among equal z the largest face index;
+//   3. the tile's shadow quads against the final z, QUAD_BATCH records staged in LDS per round,
+//      one pixel per thread: stencil +-1 in a register (obj/triangular.py:335-368);
+//   4. deferred shading of the winner (kernels_shade.h), finalise, uint8 store.
+//
+//   k_reduce_tile_stats   sums the per-tile fragment counts (only when statistics are asked for)
+#pragma once
+
+#include "kernels_bin.h"
+#include "kernels_shade.h"
+
+namespace mr {
+
+// ---- register staging: every lane fetches one primitive record of the tile's list, then the
+// records are broadcast one at a time with v_readlane (uniform values land in SGPRs, with no
+// memory latency in the inner loop and no LDS traffic).
+__device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Order-preserving key of a non-NaN double: unsigned comparison of keys == comparison of values.
+__device__ __forceinline__ unsigned long long z_key(double z)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(z);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double z_unkey(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// One small (triangle, tile) pair shared by SMALL_LANES neighbouring lanes: the samples of the
+// pixel box that lie in the tile are dealt to them round-robin (a tile of a dense mesh lists
+// 50-200 such pairs of 1-24 samples each; one lane per pair left three of the four wavefronts
+// idle behind long serial walks).  SWEEP 0: atomicMin/Max of z into the tile's LDS z-buffer.
+// SWEEP 1: the same samples again; where this face's z is the final z, atomicMax of the face
+// index.  Pairs that need the per-fragment clip test never come here (pair_class).
+constexpr int SMALL_LANES = 4;
+
+template <int SWEEP>
+__device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, int gx, int gy, bool rh,
+                                           unsigned long long *s_key, int *s_win, int sub, unsigned int &frags)
+{
+    const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
+    const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
+    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    const int bw = x1 - x0;
+    if (bw <= 0) return;
+    int px = x0 + sub, py = y0;
+    while (px >= x1) { px -= bw; ++py; }
+    while (py < y1) {
+        float u, v, w;
+        tri_bary(t, (double)px, (double)py, single, u, v, w);
+        bool ok = u >= 0 && v >= 0 && w >= 0;
+        if (ok && SWEEP == 0) ++frags;
+        if (ok) {
+            const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
+                                       t.zl0, t.zl1, t.zl2);
+            if (z == z) {                            // a NaN depth never passes the reference's test
+                const int p = (py - gy) * TILE_W + (px - gx);
+                const unsigned long long k = z_key(z);
+                if (SWEEP == 0) {
+                    if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
+                } else if (s_key[p] == k) {
+                    atomicMax(&s_win[p], t.face);
+                }
+            }
+        }
+        px += SMALL_LANES;
+        while (px >= x1) { px -= bw; ++py; }
+    }
+}
+
+// Row of the device's output buffer that screen row py (in local tile row l) lands in.  A band of
+// rows is stored top row first (the flip of obj/core.py:640).  In the striped layout (multi-GPU,
+// interleaved tile rows) every device's buffer holds out_tile_rows blocks of TILE_H rows, its
+// highest tile row first, rows inside a block top-down; the host un-permutes after the all-gather.
+__device__ __forceinline__ int out_row(const FrameConst &fc, int py, int l)
+{
+    if (fc.out_tile_rows > 0)
+        return (fc.out_tile_rows - 1 - l) * TILE_H + (tile_row_frame(fc, l) * TILE_H + TILE_H - 1 - py);
+    return fc.band_y1 - 1 - py;
+}
+
+constexpr int QUAD_STAGE_U4 = 12;     // uint4 pieces staged per quad: 64-byte header + 4 edges
+static_assert(offsetof(QuadRec, e) == 64 && sizeof(QuadEdge) == 32, "QuadRec layout");
+static_assert(QUAD_BATCH * QUAD_STAGE_U4 <= TILE_PX, "one lane stages one 16-byte piece of the batch's records");
+
+struct QuadHead {                     // the first 64 bytes of a QuadRec, as staged
+    double nx, ny, nz, d;
+    int16_t x0, x1, y0, y1;
+    int32_t n, is_front, edge;
+    uint32_t pad[3];
+};
+static_assert(sizeof(QuadHead) == 64, "QuadHead mirrors QuadRec's header");
+
+constexpr int MAT_LDS = 8;            // scenes with up to this many materials keep them in LDS
+static_assert(sizeof(Material) % 8 == 0 && MAT_LDS * sizeof(Material) / 8 <= TILE_PX, "material staging");
+
+// Heavy tiles first.  A frame's time is the slowest tile's: a tile under the mesh AND its shadow
+// volume takes 10-30x the time of a floor tile, and in plain row-major order those tiles start
+// in the middle of the launch and finish 40 us after everything else.  Frames of a sequence
+// resemble each other, so every tile leaves an estimate of its cost for the slot's NEXT frame:
+// tiles above a threshold enter one of HEAVY_CLASSES lists (heaviest class first) and are flagged.
+// The next frame's launch starts with HEAVY_FRONT extra workgroups: workgroup b of those renders
+// entry b of the lists (or exits at once if there is none), and the workgroup that owns a flagged
+// tile exits at once.  Every tile is rendered exactly once whatever the lists say, so a stale
+// history (scene or camera changed) costs time, never correctness; a new tile grid starts with an
+// empty history.  (A loop "list entry, then own tile" inside one workgroup doubled the kernel's
+// register budget: the compiler hoists the frame constants' register copies out of the loop.)
+constexpr int HEAVY_CLASSES = 3, HEAVY_MAX = 512, HEAVY_FRONT = HEAVY_CLASSES * HEAVY_MAX;
+struct TileHistory {
+    uint32_t count[HEAVY_CLASSES + 1];
+    uint32_t tiles[HEAVY_CLASSES][HEAVY_MAX];
+};
+
+// estimated cost of a tile in ~0.1 us from its list lengths (fitted to measured tile times on MI355X)
+__device__ __forceinline__ uint32_t tile_cost(uint32_t n_small, uint32_t n_big, uint32_t n_quad)
+{
+    return 30u + 3u * n_small + 15u * n_big + 6u * n_quad;
+}
+
+struct TileArgs {
+    const TriClip *clips;
+    const QuadRec *quads;
+    uint32_t *bin_count;          // cursors = list lengths; zeroed again at the end of the tile
+    const uint32_t *items[BIN_CLASSES];
+    uint32_t cap[BIN_CLASSES];
+    double *zbuf;                 // optional taps (MR_FRAME_KEEP_BUFFERS): may be null
+    int32_t *winner, *stencil;
+    uint32_t *tile_stats;
+    Counters *ctr, *next_ctr;     // this frame's counters; the next frame's (cleared here)
+    const TileHistory *hist;      // what the slot's previous frame learnt about its tiles
+    TileHistory *next_hist;       // what this frame leaves for the next
+    const uint8_t *heavy_flag;    // [n_tiles] != 0: the tile is in hist's lists
+    uint8_t *next_heavy_flag;
+};
+
+// One workgroup per tile, one pixel per thread.  Tiles are dealt to workgroups in plain
+// row-major order, i.e. round-robin over the XCDs: heavy tiles cluster on the screen, and an
+// XCD-contiguous mapping (tried first) left six of the eight XCDs idle behind the two that
+// owned the mesh and its shadow.
+__global__ void __launch_bounds__(TILE_PX)
+k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
+{
+    __shared__ unsigned long long s_key[TILE_PX];
+    __shared__ int s_win[TILE_PX];
+    __shared__ unsigned int s_cnt[TILE_STATS];
+    __shared__ uint4 s_quad[QUAD_BATCH * QUAD_STAGE_U4];
+    __shared__ uint32_t s_id[QUAD_BATCH];
+    __shared__ float s_gamma[GAMMA_LUT_SIZE];
+    __shared__ unsigned long long s_mat[MAT_LDS * sizeof(Material) / 8];
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int n_tiles = fc.tiles_x * fc.tiles_y;
+    if ((int)blockIdx.x >= n_tiles + HEAVY_FRONT) return;
+    const bool rh = fc.system == 1;
+    const bool counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
+    const TriRec *__restrict__ tris = sh.tris;
+
+    if (blockIdx.x == (uint32_t)HEAVY_FRONT && tid == 0) *ta.next_ctr = Counters{};  // nobody touches the next frame's counters before this kernel ends
+
+    // heavy tiles first (see TileHistory): entry blockIdx.x of the previous frame's lists, then the own tile
+    const uint32_t h0 = min(ta.hist->count[0], (uint32_t)HEAVY_MAX), h1 = h0 + min(ta.hist->count[1], (uint32_t)HEAVY_MAX),
+                   h2 = h1 + min(ta.hist->count[2], (uint32_t)HEAVY_MAX);
+    int tile;
+    if (blockIdx.x < (uint32_t)HEAVY_FRONT) {
+        const uint32_t b = blockIdx.x;
+        if (b >= h2) return;
+        tile = (int)(b < h0 ? ta.hist->tiles[0][b] : b < h1 ? ta.hist->tiles[1][b - h0] : ta.hist->tiles[2][b - h1]);
+    } else {
+        tile = (int)blockIdx.x - HEAVY_FRONT;
+        if (ta.heavy_flag[tile]) return;
+    }
+    s_gamma[tid] = sh.gamma_lut[tid];
+    if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
+    const bool mat_lds = fc.n_materials <= MAT_LDS;
+    if (mat_lds && tid < fc.n_materials * (int)(sizeof(Material) / 8))
+        s_mat[tid] = reinterpret_cast<const unsigned long long *>(sh.materials)[tid];
+
+    const int ltr = tile / fc.tiles_x;                    // local tile row
+    const int gx = (tile % fc.tiles_x) * TILE_W, gy = tile_row_frame(fc, ltr) * TILE_H;
+    const int lp = tid;                                   // pixel of this thread inside the tile
+    const int px = gx + (lp & (TILE_W - 1)), py = gy + lp / TILE_W;
+    const bool live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
+    const double dpx = (double)px, dpy = (double)py;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+
+    // list lengths (a list that ran over its capacity is truncated; the host grows it and re-renders)
+    const uint32_t n_small_raw = ta.bin_count[tile], n_big_raw = ta.bin_count[n_tiles + tile],
+                   n_quad_raw = ta.bin_count[2 * n_tiles + tile];
+    const uint32_t n_small = min(n_small_raw, ta.cap[0]), n_big = min(n_big_raw, ta.cap[1]), n_quad = min(n_quad_raw, ta.cap[2]);
+    const uint32_t *__restrict__ small_items = ta.items[0] + (size_t)tile * ta.cap[0];
+    const uint32_t *__restrict__ big_items = ta.items[1] + (size_t)tile * ta.cap[1];
+    const uint32_t *__restrict__ quad_items = ta.items[2] + (size_t)tile * ta.cap[2];
+    if (tid < TILE_STATS) s_cnt[tid] = 0;
+
+    // ---- 1. big pairs, one pixel per thread (obj/triangular.py:72-118)
+    double zbest = rh ? INFINITY : -INFINITY;
+    int best = -1;
+    unsigned int frags = 0;
+    for (uint32_t base = 0; base < n_big; base += WAVE) {
+        const int n = (int)min((uint32_t)WAVE, n_big - base);
+        const TriRec mine = tris[lane < n ? big_items[base + lane] : big_items[base]];
+        const int m_bx = (int)(uint16_t)mine.x0 | ((int)(uint16_t)mine.x1 << 16);
+        const int m_by = (int)(uint16_t)mine.y0 | ((int)(uint16_t)mine.y1 << 16);
+        for (int j = 0; j < n; ++j) {
+            TriRec t;
+            t.ax = bcast(mine.ax, j); t.ay = bcast(mine.ay, j);
+            t.v0x = bcast(mine.v0x, j); t.v0y = bcast(mine.v0y, j);
+            t.v1x = bcast(mine.v1x, j); t.v1y = bcast(mine.v1y, j);
+            t.d00 = bcast(mine.d00, j); t.d01 = bcast(mine.d01, j);
+            t.d11 = bcast(mine.d11, j); t.inv_den = bcast(mine.inv_den, j);
+            const int bx = bcast(m_bx, j), by = bcast(m_by, j);
+            const uint32_t flags = (uint32_t)bcast((int)mine.flags, j);
+            const int f = bcast(mine.face, j);
+            const bool single = (flags & TF_SINGLE_BOX) != 0;
+            bool in = live && px >= (bx & 0xffff) && px < (bx >> 16) && py >= (by & 0xffff) && py < (by >> 16);
+            float u, v, w;
+            tri_bary(t, dpx, dpy, single, u, v, w);
+            in = in && u >= 0 && v >= 0 && w >= 0;
+            const unsigned long long m = __ballot(in);
+            if (!m) continue;
+            frags += (unsigned int)__popcll(m);
+            if (flags & TF_CLIP) {
+                if (in) {
+                    const TriClip &c = ta.clips[f];
+                    const TriAttr &at = sh.attrs[f];
+                    double p[3];
+                    persp_bary(at.dp, u, v, w, single, p);
+                    in = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
+                }
+            }
+            const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
+                                       bcast(mine.zl0, j), bcast(mine.zl1, j), bcast(mine.zl2, j));
+            // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
+            const bool closer = rh ? (z < zbest) : (z > zbest);
+            if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
+        }
+    }
+    __syncthreads();                                      // s_cnt is zeroed, the LDS tables are loaded
+    if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
+    s_key[lp] = z_key(zbest);
+    __syncthreads();
+
+    // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
+    unsigned int sfrags = 0;
+    for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
+        const TriRec t = tris[small_items[i]];
+        small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+    }
+    if (sfrags) atomicAdd(&s_cnt[0], sfrags);
+    __syncthreads();
+
+    // winners: big pairs keep their face where their z survived, then the small pairs' sweep
+    const unsigned long long kfinal = s_key[lp];
+    s_win[lp] = (best >= 0 && kfinal == z_key(zbest)) ? best : -1;
+    __syncthreads();
+    for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
+        const TriRec t = tris[small_items[i]];
+        small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+    }
+    __syncthreads();
+    best = s_win[lp];
+    zbest = z_unkey(kfinal);
+    const bool covered = live && best >= 0;
+
+    // ---- 3. shadow quads against the final z: stencil +-1 (obj/triangular.py:335-368).  The
+    // batch's records (header and first four edges: 192 bytes each) are copied to LDS once, 16 bytes
+    // per lane, and every lane then reads the quad it is testing at the same LDS address (a
+    // broadcast read).  Adds commute, so the order of the quads never mattered
+    // (obj/triangular.py:365-368); the count stays in this thread's register.
+    int sten = 0;
+    unsigned int qfrags = 0, qupd = 0;
+    if (n_quad) {
+        // most favourable covered z of this wavefront's strip (see the depth cull below)
+        double zlim = rh ? -INFINITY : INFINITY;
+        if (!counters) {
+            if (covered) zlim = zbest;
+#pragma unroll
+            for (int off = WAVE / 2; off; off >>= 1) {
+                const double o = __shfl_xor(zlim, off);
+                zlim = rh ? fmax(zlim, o) : fmin(zlim, o);
+            }
+        }
+        for (uint32_t qbase = 0; qbase < n_quad; qbase += QUAD_BATCH) {
+            const int n = (int)min((uint32_t)QUAD_BATCH, n_quad - qbase);
+            if (qbase) __syncthreads();                   // the previous batch has been read
+            if (tid < n * QUAD_STAGE_U4) {
+                const int q = tid / QUAD_STAGE_U4, piece = tid - q * QUAD_STAGE_U4;
+                const uint32_t id = quad_items[qbase + q];
+                s_quad[tid] = reinterpret_cast<const uint4 *>(ta.quads + id)[piece];
+                if (piece == 0) s_id[q] = id;
+            }
+            __syncthreads();
+
+            // Lane j classifies quad j against this wavefront's 16x4 pixel strip with the same
+            // corner argument as quad_touches_tile: per edge, the rounded cross product is monotone
+            // in x and in y, so over the strip it is extreme at a corner.  No corner on the inner
+            // side of some edge -> no sample of the strip is inside (skip the quad); all four
+            // corners on the inner side of every edge -> every sample is inside (skip the
+            // per-pixel edge tests).  Exact, no margins.
+            bool q_reject = lane >= n, q_accept = false;
+            if (!q_reject) {
+                const QuadHead &h = *reinterpret_cast<const QuadHead *>(s_quad + lane * QUAD_STAGE_U4);
+                const QuadEdge *e = reinterpret_cast<const QuadEdge *>(s_quad + lane * QUAD_STAGE_U4 + 4);
+                const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
+                const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
+                const bool front = h.is_front != 0;
+                q_accept = h.n <= 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < 3 || h.n > 3) {
+                        const double px0 = (xa - e[i].sx) * e[i].ey, px1 = (xb - e[i].sx) * e[i].ey;
+                        const double py0 = (ya - e[i].sy) * e[i].ex, py1 = (yb - e[i].sy) * e[i].ex;
+                        const double c00 = px0 - py0, c10 = px1 - py0, c01 = px0 - py1, c11 = px1 - py1;
+                        const bool any = front ? (c00 > 0 || c10 > 0 || c01 > 0 || c11 > 0)
+                                               : (c00 < 0 || c10 < 0 || c01 < 0 || c11 < 0);
+                        const bool all = front ? (c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0)
+                                               : (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0);
+                        q_reject = q_reject || !any;
+                        q_accept = q_accept && all;
+                    }
+                }
+            }
+            if (!counters && !q_reject) {
+                // Depth cull, only when the frame is all that is asked for (no MR_FRAME_COUNTERS):
+                // the stencil matters where a triangle was drawn, and a quad changes it only where
+                // its depth passes against the z-buffer.  The quad's plane depth is affine over the
+                // screen, so over the strip -t/nz is extreme at a corner, and linearize_z is
+                // monotone while its denominator stays positive: if even the most favourable depth
+                // of the quad over the strip (pushed further by a slack that dwarfs the rounding of
+                // the per-pixel expression) loses against the most favourable covered z of the
+                // strip, no pixel of the strip can pass.  Nine in ten quad fragments fail the
+                // depth test in a typical frame.
+                const QuadHead &h = *reinterpret_cast<const QuadHead *>(s_quad + lane * QUAD_STAGE_U4);
+                const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
+                const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
+                const double t00 = (h.nx * xa + h.ny * ya) + h.d, t10 = (h.nx * xb + h.ny * ya) + h.d;
+                const double t01 = (h.nx * xa + h.ny * yb) + h.d, t11 = (h.nx * xb + h.ny * yb) + h.d;
+                const double tmin = fmin(fmin(t00, t10), fmin(t01, t11)), tmax = fmax(fmax(t00, t10), fmax(t01, t11));
+                const double inz = 1.0 / h.nz;
+                const double za = -tmin * inz, zb = -tmax * inz;
+                const double slack = 1e-12 * fmax(fabs(za), fabs(zb)) +
+                                     1e-15 * ((fabs(h.nx) * xb + fabs(h.ny) * yb) + fabs(h.d)) * fabs(inz);
+                const double zs_lo = fmin(za, zb) - slack, zs_hi = fmax(za, zb) + slack;
+                const double den_lo = fc.f_plus_n - zs_hi * fc.f_minus_n, den_hi = fc.f_plus_n - zs_lo * fc.f_minus_n;
+                // den_lo <= den <= den_hi over the strip; for 0 < den the depth two_nf / den falls as den grows
+                const bool sane = fc.two_nf > 0 && fc.f_minus_n > 0 && den_lo > 1e-9 * fc.f_plus_n;
+                const double zq_lo = fc.two_nf / den_hi * (1.0 - 1e-12), zq_hi = fc.two_nf / den_lo * (1.0 + 1e-12);
+                if (sane && (rh ? zq_lo > zlim : zq_hi < zlim)) q_reject = true;
+            }
+            unsigned long long todo = __ballot(!q_reject);
+            const unsigned long long accepted = __ballot(q_accept);
+
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                // the whole record is fetched up front with plain 16-byte broadcast reads and the
+                // tests below are combined without short-circuits: written with && the compiler
+                // kept one LDS load per condition, each behind its own branch and wait
+                const uint4 *rec = s_quad + j * QUAD_STAGE_U4;
+                const uint4 hb = rec[2];
+                const uint4 ea0 = rec[4], eb0 = rec[5], ea1 = rec[6], eb1 = rec[7], ea2 = rec[8], eb2 = rec[9],
+                            ea3 = rec[10], eb3 = rec[11];
+                const int x0 = (int)(int16_t)(hb.x & 0xffffu), x1 = (int)(int16_t)(hb.x >> 16);
+                const int y0 = (int)(int16_t)(hb.y & 0xffffu), y1 = (int)(int16_t)(hb.y >> 16);
+                const int nv = (int)hb.z;
+                const bool front = hb.w != 0;
+                bool in = live & (px >= x0) & (px < x1) & (py >= y0) & (py < y1);
+                if (!((accepted >> j) & 1)) {
+                    auto d2 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
+                    auto inner = [&](const uint4 &a, const uint4 &b) {
+                        const double ax = dpx - d2(a.x, a.y), ay = dpy - d2(a.z, a.w);
+                        const double cr = ax * d2(b.z, b.w) - ay * d2(b.x, b.y);
+                        return front ? cr > 0 : cr < 0;
+                    };
+                    const bool i0 = inner(ea0, eb0), i1 = inner(ea1, eb1), i2 = inner(ea2, eb2), i3 = inner(ea3, eb3);
+                    in = in & i0 & i1 & i2 & (i3 | (nv <= 3));
+                    if (nv > 4) {                           // clipped polygons with 5+ vertices are rare
+                        const QuadRec *q = ta.quads + s_id[j];
+                        for (int i = 4; i < nv; ++i) {
+                            const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
+                            const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
+                            in = in & (front ? cr > 0 : cr < 0);
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(in);
+                if (!m) continue;
+                qfrags += (unsigned int)__popcll(m);
+                // Depth of the quad at the sample and the test against the z-buffer
+                // (obj/triangular.py:351-360): zq = two_nf / (f_plus_n + (t / nz) * f_minus_n) with
+                // t the plane's value at the sample.  The reference's value needs two IEEE divisions;
+                // the DECISION needs none: multiplied through by nz, zbest - zq has the sign of
+                // E / D with D = f_plus_n * nz + t * f_minus_n and E = zbest * D - two_nf * nz.
+                // That settles it unless z-buffer and quad depth agree to nine digits or D is close
+                // to its pole (or something is not finite); only then is the exactly rounded
+                // expression evaluated.  t itself is computed exactly as the reference does.
+                // Decisions stay bit-exact.
+                const uint4 p0 = rec[0], p1 = rec[1];
+                const double q_nx = __hiloint2double((int)p0.y, (int)p0.x), q_ny = __hiloint2double((int)p0.w, (int)p0.z);
+                const double nzq = __hiloint2double((int)p1.y, (int)p1.x), q_d = __hiloint2double((int)p1.w, (int)p1.z);
+                const double t = (q_nx * dpx + q_ny * dpy) + q_d;
+                const double a0 = fc.f_plus_n * nzq, b0 = fc.two_nf * nzq;      // per quad
+                const double tf = t * fc.f_minus_n;
+                const double den = a0 + tf;
+                const double prod = zbest * den;
+                const double e = prod - b0;
+                // an empty z-buffer entry (+-inf) beats or loses against every finite depth
+                const bool zinf = fabs(zbest) == INFINITY;
+                bool pass = zinf ? (rh ? zbest > 0 : zbest < 0) : (rh ? ((e > 0) == (den > 0)) : ((e < 0) == (den > 0)));
+                const bool clear = zinf || fabs(e) > 1e-9 * (fabs(prod) + fabs(b0));
+                const bool unsure = in && !(clear && fabs(den) > 2e-4 * (fabs(a0) + fabs(tf)));
+                if (__ballot(unsure)) {
+                    if (unsure) {
+                        const double z = linearize_z(fc, -t / nzq);
+                        pass = rh ? (zbest >= z) : (zbest <= z);
+                    }
+                }
+                pass = pass && in;
+                qupd += (unsigned int)__popcll(__ballot(pass));
+                sten += pass ? (front ? 1 : -1) : 0;
+            }
+        }
+    }
+
+    // ---- 4. deferred shading + finalise (kernels_shade.h; obj/core.py:640)
+    const bool lit = (int16_t)sten == 0;                  // the reference's buffer is int16
+    if (live) {
+        float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
+        bool ready_u8 = false;
+        if (best >= 0) {
+            const TriRec t = tris[best];
+            const TriAttr &at = sh.attrs[best];
+            const Material *mp = mat_lds ? reinterpret_cast<const Material *>(s_mat) + t.material
+                                         : sh.materials + t.material;
+            shade_pixel(fc, t, at, *mp, px, py, lit, rgb);
+        } else if ((fc.flags & MR_FRAME_SKYBOX) && sh.sky) {
+            sky_color(fc, sh.sky, px, py, rgb);
+        } else if (fc.background_u8 >> 24) {
+            ready_u8 = true;       // the host already finalised the colour with NumPy itself (obj/core.py:600,640)
+        }
+        const size_t at_px = (size_t)py * fc.width + px;
+        if (sh.frame) { sh.frame[at_px * 3 + 0] = rgb[0]; sh.frame[at_px * 3 + 1] = rgb[1]; sh.frame[at_px * 3 + 2] = rgb[2]; }
+        uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
+        if (ready_u8) {
+            o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
+        }
+        if (ta.zbuf) {                                    // taps for the parity tests / per-face status / overlay
+            ta.zbuf[at_px] = zbest;
+            ta.winner[at_px] = best;
+            ta.stencil[at_px] = sten;
+        }
+    }
+
+    // ---- per-tile statistics and housekeeping
+    if (counters) {
+        const unsigned long long cov = __ballot(covered), litm = __ballot(covered && lit);
+        if (lane == 0) {
+            if (cov) atomicAdd(&s_cnt[3], (unsigned int)__popcll(cov));
+            if (litm) atomicAdd(&s_cnt[4], (unsigned int)__popcll(litm));
+            if (qfrags) atomicAdd(&s_cnt[1], qfrags);
+            if (qupd) atomicAdd(&s_cnt[2], qupd);
+        }
+    }
+    __syncthreads();
+    // per-tile partial counts, summed by k_reduce_tile_stats (thousands of workgroups adding to
+    // one cache line of counters would serialise at the memory side)
+    uint32_t *rec = ta.tile_stats + (size_t)tile * TILE_REC;
+    if (tid < TILE_STATS) rec[tid] = s_cnt[tid];
+    if (tid == 0) {                                       // list lengths; timing for mr_debug_read_tile_records
+        rec[5] = n_small_raw; rec[6] = n_big_raw; rec[7] = n_quad_raw;
+        rec[8] = (uint32_t)t_start;
+        rec[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        rec[10] = rec[11] = 0;
+        if (n_small_raw > ta.cap[0]) { atomicOr(&ta.ctr->overflow, 1u); atomicMax(&ta.ctr->max_list[0], n_small_raw); }
+        if (n_big_raw > ta.cap[1]) { atomicOr(&ta.ctr->overflow, 2u); atomicMax(&ta.ctr->max_list[1], n_big_raw); }
+        if (n_quad_raw > ta.cap[2]) { atomicOr(&ta.ctr->overflow, 4u); atomicMax(&ta.ctr->max_list[2], n_quad_raw); }
+    }
+    if (tid < BIN_CLASSES) ta.bin_count[tid * n_tiles + tile] = 0;   // cursors zeroed for the next frame
+    if (tid == 0) {                                       // what the slot's next frame should know about this tile
+        const uint32_t cost = tile_cost(n_small_raw, n_big_raw, n_quad_raw);
+        const int cls = cost >= 480u ? 0 : cost >= 240u ? 1 : cost >= 120u ? 2 : -1;
+        uint8_t flag = 0;
+        if (cls >= 0) {
+            const uint32_t at = atomicAdd(&ta.next_hist->count[cls], 1u);
+            if (at < (uint32_t)HEAVY_MAX) { ta.next_hist->tiles[cls][at] = (uint32_t)tile; flag = 1; }
+            else atomicSub(&ta.next_hist->count[cls], 1u);
+        }
+        ta.next_heavy_flag[tile] = flag;
+    }
+}
+
+// Sums the per-tile partial counts and list lengths into the frame counters; grid-stride over
+// tiles, one atomic per workgroup and counter; run only when the statistics are asked for.
+__global__ void __launch_bounds__(256)
+k_reduce_tile_stats(const uint32_t *__restrict__ tile_stats, int n_tiles, Counters *__restrict__ ctr)
+{
+    constexpr int NS = TILE_STATS + 2;                    // + triangle pairs, all pairs
+    __shared__ unsigned long long part[NS][256 / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + tid, gsz = (size_t)gridDim.x * blockDim.x;
+    unsigned long long acc[NS] = {};
+    for (size_t t = gid; t < (size_t)n_tiles; t += gsz) {
+        const uint32_t *rec = tile_stats + t * TILE_REC;
+#pragma unroll
+        for (int k = 0; k < TILE_STATS; ++k) acc[k] += rec[k];
+        acc[TILE_STATS] += (unsigned long long)rec[5] + rec[6];
+        acc[TILE_STATS + 1] += (unsigned long long)rec[5] + rec[6] + rec[7];
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        unsigned long long v = acc[k];
+        for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) part[k][wv] = v;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        unsigned long long v = 0;
+        for (int w = 0; w < 256 / WAVE; ++w) v += part[tid][w];
+        if (tid < TILE_STATS) {
+            unsigned long long *dst = tid == 0 ? &ctr->frag_tri : tid == 1 ? &ctr->frag_quad
+                                    : tid == 2 ? &ctr->stencil_updates : tid == 3 ? &ctr->covered_px : &ctr->lit_px;
+            if (v) atomicAdd(dst, v);
+        } else if (v) {
+            atomicAdd(tid == TILE_STATS ? &ctr->tri_bin_total : &ctr->bin_total, (unsigned int)v);
+        }
+    }
+}
+
+}  // namespace mr

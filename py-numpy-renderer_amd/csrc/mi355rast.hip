@@ -1,16 +1,17 @@
 // mi355rast.hip -- C ABI (include/mi355rast.h) and host-side frame orchestration.
 //
 // One process drives one GPU.  A scene keeps its static arrays (vertices, attributes, index
-// arrays, textures, the unique-edge table for silhouettes) resident in HBM; a frame is a fixed
-// sequence of kernels on one HIP stream, with no host synchronisation in between:
+// arrays, textures, the unique-edge table with the incident faces' normals) resident in HBM; a
+// frame is THREE kernels on one HIP stream, with no host synchronisation in between:
 //
-//   k_vertex_mfma (+ light-facing flags) -> k_tri_setup (+ bin count of its faces; + silhouette search)
-//     -> [k_quad_setup (+ work items of its quads)] -> k_bin_large_and_count -> k_scan_bins -> k_bin_fill
-//     -> k_tile_raster -> [k_tile_quads] -> k_shade -> (D2H of the uint8 band for mr_render)
+//   k_setup     faces: vertex transform, cull, set-up records, own tile lists
+//               edges: silhouette search, shadow-quad extrusion / clip / projection
+//   k_bin_work  tile lists of the large primitives (floor triangles, shadow quads)
+//   k_tile      per 16x16 tile: coverage + z + winner, stencil count, shading, finalise -> uint8
+//   (D2H of the uint8 rows for mr_render)
 //
 // Per-frame work buffers live in a "frame slot".  Every stream a caller renders on gets its own
-// slot, so frames enqueued on different streams are independent and may overlap on the device
-// (the stages of one frame are short, latency-bound kernels that leave most CUs idle).
+// slot, so frames enqueued on different streams are independent and may overlap on the device.
 //
 // Built for gfx950 only, with -ffp-contract=off (see rast_math.h).
 #include "../../include/mi355rast.h"
@@ -29,8 +30,7 @@
 
 #include "rast_types.h"
 #include "kernels_geometry.h"
-#include "kernels_raster.h"
-#include "kernels_shade.h"
+#include "kernels_tile.h"
 
 namespace {
 
@@ -79,17 +79,17 @@ struct EdgeKey {
 };
 
 // Event marks of one frame:
-//   0 start | 1 vertex + light flags | 2 face set-up + silhouettes | 3 quad set-up | 4 work-item count + survivor counts |
-//   5 bin scan+fill | 6 tile raster | 7 tile quads | 8 shade | 9 device->host copy
-constexpr int EVENT_RING = 64, N_MARKS = 10;
+//   0 start | 1 after k_vertex_mfma (optional) | 2 after k_setup | 3 after k_bin_work | 4 after k_tile | 5 device->host copy
+constexpr int EVENT_RING = 64, N_MARKS = 6;
 
 // Everything one in-flight frame writes.
 struct FrameSlot {
     hipStream_t stream = nullptr;                 // the stream this slot serves
-    DevBuf d_vout, d_vclip, d_tris, d_clips, d_status, d_lit, d_valid, d_count_list, d_quads, d_sil, d_counters;
-    DevBuf d_bin_count, d_bin_offset, d_scan_part, d_items, d_work, d_quad_work, d_tile_stats;
+    DevBuf d_vout, d_vclip, d_tris, d_attrs, d_clips, d_status, d_count_list, d_quads, d_sil, d_counters;
+    DevBuf d_bin_count, d_items[mr::BIN_CLASSES], d_work, d_tile_stats, d_hist, d_heavy_flag;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
-    uint32_t item_cap = 0, work_cap = 0, quad_cap = 0, quad_work_cap = 0;
+    // capacities this slot's buffers were last bound with (the scene holds the current ones)
+    uint32_t bin_cap[mr::BIN_CLASSES] = { 0, 0, 0 }, work_cap = 0, quad_cap = 0;
     int bins_zeroed_for = 0;
 
     mr::Counters *h_counters = nullptr;           // pinned
@@ -102,11 +102,11 @@ struct FrameSlot {
     int last_n_tiles = 0;
     bool have_frame = false, stats_reduced = false;
 
-    void reset_caps() { item_cap = work_cap = quad_cap = quad_work_cap = 0; bins_zeroed_for = 0; have_frame = false; }
+    void reset_caps() { bins_zeroed_for = 0; have_frame = false; }
     void release()
     {
-        DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_clips, &d_status, &d_lit, &d_valid, &d_quads, &d_sil, &d_counters,
-                           &d_bin_count, &d_bin_offset, &d_scan_part, &d_items, &d_work, &d_quad_work, &d_tile_stats,
+        DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_attrs, &d_clips, &d_status, &d_quads, &d_sil, &d_counters,
+                           &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_heavy_flag,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
         if (events_ok) {
@@ -115,6 +115,8 @@ struct FrameSlot {
             events_ok = false;
         }
     }
+    // the counters are double-buffered by frame parity: a frame's tile kernel clears the next frame's
+    mr::Counters *ctr(uint64_t frame) const { return d_counters.as<mr::Counters>() + (frame & 1); }
 };
 
 constexpr int MAX_SLOTS = 16;
@@ -131,11 +133,14 @@ struct mr_scene {
     std::vector<mr::Texture> textures;       // device pointers
     std::vector<void *> texture_allocs;
     std::vector<ModelInfo> models;
-    std::vector<uint32_t> edge_offset, edge_inc;
+    std::vector<int32_t> edge_ids;            // per face corner: raw vertex identity for silhouette edges (made unique per model)
+    std::vector<int32_t> edge_raw;            // the same as the caller passed it (for mr_read_silhouette)
+    std::vector<mr::EdgeRec> edges;           // unique undirected edges, scrambled order
+    std::vector<uint32_t> edge_inc;           // incidences beyond an edge's first two
     bool dirty = true;
 
     // ---- device copies of the static scene
-    DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edge_offset, d_edge_inc;
+    DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edges, d_edge_inc, d_face_n;
     DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
     DevBuf d_gamma;                          // GAMMA_LUT_SIZE float32 thresholds of the finalise step function
     int32_t sky_size = 0;
@@ -145,6 +150,11 @@ struct mr_scene {
     FrameSlot *last = nullptr;               // slot of the most recently enqueued frame
     mr_stats stats = {};
     int n_silhouette = 0;
+    // Capacities of the per-frame work lists, shared by all slots: what one frame learnt (a tile with
+    // a longer list, more silhouette edges) holds for the frames rendered on other streams too.
+    uint32_t bin_cap[mr::BIN_CLASSES] = { 512u, 128u, 256u };   // entries per tile and class
+    uint32_t work_cap = 1u << 18, quad_cap = 0;
+    void reset_caps() { bin_cap[0] = 512u; bin_cap[1] = 128u; bin_cap[2] = 256u; work_cap = 1u << 18; quad_cap = 0; }
 };
 
 namespace {
@@ -170,30 +180,47 @@ int upload(DevBuf &buf, const std::vector<T> &v, hipStream_t s)
 }
 
 // Unique undirected edges with their incident (face, corner) pairs in face order: what the
-// reference's per-model set of Edge objects (obj/triangular.py:286-302) reduces to.
+// reference's per-model set of Edge objects (obj/triangular.py:286-302) reduces to.  An edge is
+// identified by the RAW vertex ids of its corners (mr_model_desc.edge_ids), as in the reference.
+// The table is stored in a scrambled order (sorted by a hash of the edge): silhouettes run along
+// consecutive vertex indices, and a wavefront of k_setup that found dozens of silhouette edges
+// among its 64 would set their quads up four at a time while the rest of the device idles.
 void build_edge_table(mr_scene *sc)
 {
     const size_t nf = sc->faces.size() / 12;
     std::vector<EdgeKey> keys;
     keys.reserve(nf * 3);
     for (size_t f = 0; f < nf; ++f) {
-        const int32_t *fc = &sc->faces[f * 12];
+        const int32_t *id = &sc->edge_ids[f * 3];
         for (int k = 0; k < 3; ++k) {
-            uint32_t a = (uint32_t)fc[k * 4], b = (uint32_t)fc[((k + 1) % 3) * 4];
+            uint32_t a = (uint32_t)id[k], b = (uint32_t)id[(k + 1) % 3];
             uint32_t lo = std::min(a, b), hi = std::max(a, b);
             keys.push_back({ ((uint64_t)lo << 32) | hi, (uint32_t)(f * 4 + k) });
         }
     }
+    auto scramble = [](uint64_t k) {                   // splitmix64 finaliser: a bijection
+        k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 27; k *= 0x94d049bb133111ebull; k ^= k >> 31;
+        return k;
+    };
+    for (EdgeKey &e : keys) e.key = scramble(e.key);
     std::sort(keys.begin(), keys.end(), [](const EdgeKey &x, const EdgeKey &y) {
         return x.key != y.key ? x.key < y.key : x.inc < y.inc;
     });
-    sc->edge_offset.clear();
-    sc->edge_inc.resize(keys.size());
-    for (size_t i = 0; i < keys.size(); ++i) {
-        if (i == 0 || keys[i].key != keys[i - 1].key) sc->edge_offset.push_back((uint32_t)i);
-        sc->edge_inc[i] = keys[i].inc;
+    sc->edges.clear();
+    sc->edge_inc.clear();
+    for (size_t i = 0; i < keys.size();) {
+        size_t j = i;
+        while (j < keys.size() && keys[j].key == keys[i].key) ++j;
+        mr::EdgeRec r;
+        std::memset(&r, 0, sizeof r);
+        r.inc[0] = keys[i].inc;
+        r.inc[1] = j - i > 1 ? keys[i + 1].inc : 0xffffffffu;
+        r.extra_off = (uint32_t)sc->edge_inc.size();
+        r.extra_cnt = j - i > 2 ? (uint32_t)(j - i - 2) : 0u;
+        for (size_t k = i + 2; k < j; ++k) sc->edge_inc.push_back(keys[k].inc);
+        sc->edges.push_back(r);
+        i = j;
     }
-    sc->edge_offset.push_back((uint32_t)keys.size());
 }
 
 // Finalise is uint8(frame ** 0.8 * 255) in float32 (obj/core.py:640): a monotone step function
@@ -243,8 +270,18 @@ int commit(mr_scene *sc)
     if ((rc = upload(sc->d_face_flags, sc->face_flags, g_stream))) return rc;
     if ((rc = upload(sc->d_materials, sc->materials, g_stream))) return rc;
     if ((rc = upload(sc->d_textures, sc->textures, g_stream))) return rc;
-    if ((rc = upload(sc->d_edge_offset, sc->edge_offset, g_stream))) return rc;
+    if ((rc = upload(sc->d_edges, sc->edges, g_stream))) return rc;
     if ((rc = upload(sc->d_edge_inc, sc->edge_inc, g_stream))) return rc;
+    // static per scene: the faces' unit normals (light-facing test), copied into the edge records
+    const int nf = (int)(sc->faces.size() / 12), ne = (int)sc->edges.size();
+    HIP_TRY(sc->d_face_n.ensure(std::max<size_t>((size_t)nf * 4 * sizeof(double), 16)));
+    if (nf > 0)
+        hipLaunchKernelGGL(mr::k_face_normals, dim3((nf + 255) / 256), dim3(256), 0, g_stream, nf, sc->d_faces.as<int32_t>(),
+                           sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_face_n.as<double>());
+    if (ne > 0)
+        hipLaunchKernelGGL(mr::k_edge_normals, dim3((ne + 255) / 256), dim3(256), 0, g_stream, ne, sc->d_edges.as<mr::EdgeRec>(),
+                           sc->d_face_n.as<double>());
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g_stream));
     sc->dirty = false;
     return MR_OK;
@@ -270,6 +307,14 @@ int validate_frame(const mr_frame_desc *fr)
     if (fr->row_begin < 0 || fr->row_end > fr->height || fr->row_begin >= fr->row_end)
         return fail(MR_E_INVALID, "row band must satisfy 0 <= row_begin < row_end <= height");
     if (fr->light_type < 0 || fr->light_type > 2) return fail(MR_E_INVALID, "unknown light type");
+    if (fr->stripe_count > 1) {
+        if (fr->stripe_index < 0 || fr->stripe_index >= fr->stripe_count)
+            return fail(MR_E_INVALID, "stripe_index must satisfy 0 <= stripe_index < stripe_count");
+        if (fr->row_begin != 0 || fr->row_end != fr->height)
+            return fail(MR_E_INVALID, "a striped frame spans all rows: row_begin / row_end must be 0 / height");
+    } else if (fr->stripe_count < 0) {
+        return fail(MR_E_INVALID, "stripe_count must not be negative");
+    }
     return MR_OK;
 }
 
@@ -282,12 +327,24 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
     // output rows count from the top, the reference's buffers from the bottom (obj/core.py:640 flips)
     fc.band_y0 = fr->height - fr->row_end;
     fc.band_y1 = fr->height - fr->row_begin;
-    fc.tile_y0 = fc.band_y0 / mr::TILE_H;
     fc.tiles_x = (fr->width + mr::TILE_W - 1) / mr::TILE_W;
-    fc.tiles_y = (fc.band_y1 - 1) / mr::TILE_H + 1 - fc.tile_y0;
+    if (fr->stripe_count > 1) {
+        // interleaved tile rows: this device owns frame tile rows stripe_index, stripe_index + N, ...
+        const int rows = (fr->height + mr::TILE_H - 1) / mr::TILE_H;
+        fc.tile_y0 = fr->stripe_index;
+        fc.tile_step = fr->stripe_count;
+        fc.tiles_y = rows > fr->stripe_index ? (rows - 1 - fr->stripe_index) / fr->stripe_count + 1 : 0;
+        fc.out_tile_rows = (rows + fr->stripe_count - 1) / fr->stripe_count;
+    } else {
+        fc.tile_y0 = fc.band_y0 / mr::TILE_H;
+        fc.tile_step = 1;
+        fc.tiles_y = (fc.band_y1 - 1) / mr::TILE_H + 1 - fc.tile_y0;
+        fc.out_tile_rows = 0;
+    }
     fc.n_vertices = (int32_t)(sc->verts.size() / 4);
     fc.n_faces = (int32_t)(sc->faces.size() / 12);
-    fc.n_edges = sc->edge_offset.empty() ? 0 : (int32_t)sc->edge_offset.size() - 1;
+    fc.n_edges = (int32_t)sc->edges.size();
+    fc.n_materials = (int32_t)sc->materials.size();
     std::memcpy(fc.mvp, fr->mvp, sizeof fc.mvp);
     std::memcpy(fc.viewport, fr->viewport, sizeof fc.viewport);
     std::memcpy(fc.debug_mvp, fr->debug_mvp, sizeof fc.debug_mvp);
@@ -314,55 +371,68 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
 
 inline unsigned blocks_for(long long n, int per_block) { return (unsigned)std::max<long long>(1, (n + per_block - 1) / per_block); }
 
-// Enqueues one frame on the slot's stream.  d_out receives the uint8 band.
+// bytes of the uint8 output of a frame: the band's rows, or the striped layout's blocks
+size_t out_bytes(const mr_frame_desc *fr)
+{
+    if (fr->stripe_count > 1) {
+        const int rows = (fr->height + mr::TILE_H - 1) / mr::TILE_H;
+        return (size_t)((rows + fr->stripe_count - 1) / fr->stripe_count) * mr::TILE_H * fr->width * 3;
+    }
+    return (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
+}
+
+// Enqueues one frame on the slot's stream.  d_out receives the uint8 rows.
 int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t *d_out)
 {
     using namespace mr;
     int rc = commit(sc);
     if (rc) return rc;
     hipStream_t stream = fs->stream;
-    const FrameConst fc = make_const(sc, fr);
+    FrameConst fc = make_const(sc, fr);
+    if (fc.flags & MR_FRAME_FACE_STATUS) fc.flags |= MR_FRAME_KEEP_BUFFERS;
     const size_t npx = (size_t)fc.width * fc.height;
     const int n_tiles = fc.tiles_x * fc.tiles_y;
     const bool shadows = (fc.flags & MR_FRAME_SHADOWS) != 0;
+    const bool keep = (fc.flags & MR_FRAME_KEEP_BUFFERS) != 0;
     const size_t nF = (size_t)std::max(fc.n_faces, 1), nV = (size_t)std::max(fc.n_vertices, 1);
+    // MR_VERTEX_PATH=mfma: vertex transform once per unique vertex on the matrix cores, as a launch of
+    // its own in front of k_setup (same bits; for A/B timing and the MFMA counters)
+    static const bool vertex_mfma = [] { const char *e = getenv("MR_VERTEX_PATH"); return e && !strcmp(e, "mfma"); }();
 
-    if (fs->quad_cap == 0) fs->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
-    if (fs->item_cap == 0) fs->item_cap = (uint32_t)std::max<size_t>(4 * nF + 8 * (size_t)n_tiles, 1u << 22);
-    if (fs->work_cap == 0) fs->work_cap = 1u << 18;
-    if (fs->quad_work_cap == 0) fs->quad_work_cap = (uint32_t)n_tiles + (1u << 16);
+    if (sc->quad_cap == 0) sc->quad_cap = (uint32_t)std::min<size_t>(std::max(fc.n_edges, 1), 1u << 17);
+    fs->quad_cap = sc->quad_cap; fs->work_cap = sc->work_cap;
+    for (int c = 0; c < BIN_CLASSES; ++c) fs->bin_cap[c] = sc->bin_cap[c];
 
-    HIP_TRY(fs->d_vout.ensure(nV * sizeof(VertexOut)));
-    HIP_TRY(fs->d_vclip.ensure(nV * sizeof(VertexClip)));
+    if (vertex_mfma) {
+        HIP_TRY(fs->d_vout.ensure(nV * sizeof(VertexOut)));
+        HIP_TRY(fs->d_vclip.ensure(nV * sizeof(VertexClip)));
+    }
     HIP_TRY(fs->d_count_list.ensure(nF * sizeof(uint32_t)));
     HIP_TRY(fs->d_tris.ensure(nF * sizeof(TriRec)));
+    HIP_TRY(fs->d_attrs.ensure(nF * sizeof(TriAttr)));
     HIP_TRY(fs->d_clips.ensure(nF * sizeof(TriClip)));
     HIP_TRY(fs->d_status.ensure(nF));
-    HIP_TRY(fs->d_lit.ensure(nF));
-    HIP_TRY(fs->d_valid.ensure(nF * sizeof(uint32_t)));
     HIP_TRY(fs->d_quads.ensure((size_t)fs->quad_cap * sizeof(QuadRec)));
-    HIP_TRY(fs->d_sil.ensure((size_t)fs->quad_cap * 3 * sizeof(int32_t)));
-    HIP_TRY(fs->d_counters.ensure(sizeof(Counters)));
-    HIP_TRY(fs->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
-    HIP_TRY(fs->d_bin_offset.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
-    const int scan_blocks = blocks_for(BIN_CLASSES * n_tiles, SCAN_ITEMS) > 0 ? blocks_for(BIN_CLASSES * n_tiles, SCAN_ITEMS) : 1;
-    // k_scan_bins' workgroups wait for their predecessors' totals, so all of them must be able to be
-    // resident at once (256 CUs x 8): beyond ~350 000 tiles (a 9 400 x 9 400 px band) render in row bands
-    if (scan_blocks > 1024)
-        return fail(MR_E_UNSUPPORTED, "band too large for one pass (more than 349 525 tiles of 16x16 px): render it in row bands");
+    HIP_TRY(fs->d_sil.ensure((size_t)fs->quad_cap * 2 * sizeof(int32_t)));
     {
-        const void *had = fs->d_scan_part.p;
-        HIP_TRY(fs->d_scan_part.ensure((size_t)scan_blocks * 8));
-        if (fs->d_scan_part.p != had)       // epoch tags start below every frame's epoch (>= 1)
-            HIP_TRY(hipMemsetAsync(fs->d_scan_part.p, 0, fs->d_scan_part.cap, stream));
+        const void *had = fs->d_counters.p;
+        HIP_TRY(fs->d_counters.ensure(2 * sizeof(Counters)));
+        if (fs->d_counters.p != had) HIP_TRY(hipMemsetAsync(fs->d_counters.p, 0, fs->d_counters.cap, stream));
     }
-    HIP_TRY(fs->d_items.ensure((size_t)fs->item_cap * 4));
+    HIP_TRY(fs->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
+    for (int c = 0; c < BIN_CLASSES; ++c) {
+        const size_t bytes = (size_t)std::max(n_tiles, 1) * fs->bin_cap[c] * 4;
+        if (bytes > ((size_t)48 << 30))
+            return fail(MR_E_OVERFLOW, "more primitives in one 16x16 tile than the tile lists are allowed to grow to (48 GB per class)");
+        HIP_TRY(fs->d_items[c].ensure(bytes));
+    }
     HIP_TRY(fs->d_work.ensure((size_t)fs->work_cap * sizeof(uint2)));
-    HIP_TRY(fs->d_quad_work.ensure((size_t)fs->quad_work_cap * sizeof(uint4)));
-    HIP_TRY(fs->d_tile_stats.ensure((size_t)n_tiles * TILE_REC * 4));
-    HIP_TRY(fs->d_z.ensure(npx * sizeof(double)));
-    HIP_TRY(fs->d_winner.ensure(npx * sizeof(int32_t)));
-    HIP_TRY(fs->d_stencil.ensure(npx * sizeof(int32_t)));
+    HIP_TRY(fs->d_tile_stats.ensure((size_t)std::max(n_tiles, 1) * TILE_REC * 4));
+    if (keep) {
+        HIP_TRY(fs->d_z.ensure(npx * sizeof(double)));
+        HIP_TRY(fs->d_winner.ensure(npx * sizeof(int32_t)));
+        HIP_TRY(fs->d_stencil.ensure(npx * sizeof(int32_t)));
+    }
     if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(fs->d_frame.ensure(npx * 3 * sizeof(float)));
     if (!fs->events_ok) {
         for (auto &set : fs->ev_ring) for (auto &e : set) HIP_TRY(hipEventCreate(&e));
@@ -371,117 +441,101 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     }
     fs->ev = fs->ev_ring[fs->frames_enqueued % EVENT_RING];
 
-    Counters *ctr = fs->d_counters.as<Counters>();
-    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the visibility / shading kernels
+    Counters *ctr = fs->ctr(fs->frames_enqueued), *next_ctr = fs->ctr(fs->frames_enqueued + 1);
+    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the tile kernel
     const bool all_marks = !(fc.flags & MR_FRAME_LIGHT_TIMING);
     HIP_TRY(hipEventRecord(fs->ev[0], stream));
-    // The bin cursors are left zeroed by k_tile_raster and the frame counters are cleared by
-    // k_vertex, so a steady-state frame issues no memset; only a new tile grid needs one.
+    // The list cursors are left zeroed by k_tile and the frame counters are cleared by the previous
+    // frame's k_tile, so a steady-state frame issues no memset; only a new tile grid needs one.
+    HIP_TRY(fs->d_hist.ensure(2 * sizeof(TileHistory)));
+    HIP_TRY(fs->d_heavy_flag.ensure(2 * (size_t)std::max(n_tiles, 1)));
     if (fs->bins_zeroed_for != BIN_CLASSES * n_tiles + 1) {
         HIP_TRY(hipMemsetAsync(fs->d_bin_count.p, 0, fs->d_bin_count.cap, stream));
+        HIP_TRY(hipMemsetAsync(fs->d_hist.p, 0, fs->d_hist.cap, stream));       // no history for a new tile grid
+        HIP_TRY(hipMemsetAsync(fs->d_heavy_flag.p, 0, fs->d_heavy_flag.cap, stream));
         fs->bins_zeroed_for = BIN_CLASSES * n_tiles + 1;
     }
+    const unsigned par = (unsigned)(fs->frames_enqueued & 1);
+    TileHistory *hist = fs->d_hist.as<TileHistory>() + par, *next_hist = fs->d_hist.as<TileHistory>() + (par ^ 1u);
+    // this frame's tile kernel fills next_hist; its counts are cleared first (the previous frame is done reading it)
+    HIP_TRY(hipMemsetAsync(next_hist->count, 0, sizeof(next_hist->count), stream));
 
-    // ---- geometry
-    // vertex transform on the matrix cores (v_mfma_f64_16x16x4_f64, 16 vertices per wavefront);
-    // MR_VERTEX_PATH=valu selects the VALU fma-chain kernel instead (same bits, for A/B timing).
-    // The light-facing flags of the faces (for the silhouettes) are extra workgroups of this launch.
-    static const bool vertex_valu = [] { const char *e = getenv("MR_VERTEX_PATH"); return e && !strcmp(e, "valu"); }();
-    const unsigned lit_blocks = (shadows && fc.n_faces > 0) ? blocks_for(fc.n_faces, 256) : 0u;
-    if (vertex_valu) {
-        const unsigned vb = blocks_for(fc.n_vertices, 256);
-        hipLaunchKernelGGL(k_vertex, dim3(vb + lit_blocks), dim3(256), 0, stream, fc, sc->d_verts.as<double>(),
-                           fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr, sc->d_faces.as<int32_t>(),
-                           sc->d_face_flags.as<uint8_t>(), fs->d_lit.as<uint8_t>(), vb);
-    } else {
-        const unsigned vb = blocks_for(fc.n_vertices, 64);
-        hipLaunchKernelGGL(k_vertex_mfma, dim3(vb + lit_blocks), dim3(256), 0, stream, fc, sc->d_verts.as<double>(),
-                           fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), ctr, sc->d_faces.as<int32_t>(),
-                           sc->d_face_flags.as<uint8_t>(), fs->d_lit.as<uint8_t>(), vb);
-    }
-    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
-    // binning arguments (kernels_bin.h): k_tri_setup and k_quad_setup run its count pass for their primitives
     BinArgs ba;
-    ba.tris = fs->d_tris.as<TriRec>(); ba.valid_list = fs->d_valid.as<uint32_t>();
-    ba.quads = fs->d_quads.as<QuadRec>();
+    ba.tris = fs->d_tris.as<TriRec>(); ba.quads = fs->d_quads.as<QuadRec>();
     ba.ctr = ctr; ba.quad_cap = fs->quad_cap;
-    ba.bin_count = fs->d_bin_count.as<uint32_t>(); ba.bin_offset = fs->d_bin_offset.as<uint32_t>();
-    ba.items = fs->d_items.as<uint32_t>(); ba.item_cap = fs->item_cap;
+    ba.bin_count = fs->d_bin_count.as<uint32_t>();
+    for (int c = 0; c < BIN_CLASSES; ++c) { ba.items[c] = fs->d_items[c].as<uint32_t>(); ba.cap[c] = fs->bin_cap[c]; }
     ba.work = fs->d_work.as<uint2>(); ba.work_cap = fs->work_cap;
-    ba.quad_work = fs->d_quad_work.as<uint4>(); ba.quad_work_cap = fs->quad_work_cap;
+
+    SetupArgs sa;
+    sa.faces = sc->d_faces.as<int32_t>(); sa.face_flags = sc->d_face_flags.as<uint8_t>();
+    sa.verts = sc->d_verts.as<double>(); sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
+    sa.vout = fs->d_vout.as<VertexOut>(); sa.vclip = fs->d_vclip.as<VertexClip>();
+    sa.tris = fs->d_tris.as<TriRec>(); sa.attrs = fs->d_attrs.as<TriAttr>(); sa.clips = fs->d_clips.as<TriClip>();
+    sa.status = fs->d_status.as<uint8_t>(); sa.count_list = fs->d_count_list.as<uint32_t>(); sa.ctr = ctr;
+    sa.edges = sc->d_edges.as<EdgeRec>(); sa.edge_inc = sc->d_edge_inc.as<uint32_t>(); sa.face_n = sc->d_face_n.as<double>();
+    sa.sil_edges = fs->d_sil.as<int32_t>(); sa.quads = fs->d_quads.as<QuadRec>(); sa.quad_cap = fs->quad_cap;
+
+    // ---- 1. set-up: faces and (with shadows) edges, one launch
+    if (vertex_mfma && fc.n_vertices > 0)
+        hipLaunchKernelGGL(k_vertex_mfma, dim3(blocks_for(fc.n_vertices, 64)), dim3(256), 0, stream, fc,
+                           sc->d_verts.as<double>(), fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>());
+    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
     {
-        // face set-up and silhouette search are independent: one launch
-        const unsigned setup_blocks = blocks_for(fc.n_faces, SETUP_BLOCK);
-        const unsigned sil_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, SETUP_BLOCK) : 0u;
-        if (setup_blocks + sil_blocks > 0)
-            hipLaunchKernelGGL(k_tri_setup, dim3(setup_blocks + sil_blocks), dim3(SETUP_BLOCK), 0, stream, fc,
-                               sc->d_faces.as<int32_t>(), sc->d_face_flags.as<uint8_t>(),
-                               fs->d_vout.as<VertexOut>(), fs->d_vclip.as<VertexClip>(), fs->d_tris.as<TriRec>(),
-                               fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(),
-                               fs->d_valid.as<uint32_t>(), fs->d_count_list.as<uint32_t>(), ctr, ba, setup_blocks,
-                               sc->d_edge_offset.as<uint32_t>(), sc->d_edge_inc.as<uint32_t>(),
-                               fs->d_lit.as<uint8_t>(), fs->d_sil.as<int32_t>(), fs->quad_cap);
+        const unsigned face_blocks = fc.n_faces > 0 ? blocks_for(fc.n_faces, SETUP_BLOCK) : 0u;
+        const unsigned edge_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, SETUP_BLOCK) : 0u;
+        if (face_blocks + edge_blocks > 0) {
+            if (vertex_mfma)
+                hipLaunchKernelGGL(k_setup<true>, dim3(face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
+            else
+                hipLaunchKernelGGL(k_setup<false>, dim3(face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
+        }
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
-    if (shadows && fc.n_edges > 0) {
-        const long long max_sil = std::min<long long>(fc.n_edges, fs->quad_cap);
-        hipLaunchKernelGGL(k_quad_setup, dim3((unsigned)std::min<long long>(1024, blocks_for(max_sil * QS_LANES, 64))),
-                           dim3(64), 0, stream, fc, fs->d_sil.as<int32_t>(), sc->d_verts.as<double>(),
-                           fs->d_quads.as<QuadRec>(), fs->quad_cap, ctr, ba);
+
+    // ---- 2. tile lists of the large primitives + leftover survivor counts (one wavefront per face,
+    // grid-stride, up to 512 workgroups: a mesh of large faces lists most of them)
+    {
+        const unsigned work_blocks = 512;
+        const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
+        hipLaunchKernelGGL(k_bin_work, dim3(count_blocks + work_blocks), dim3(256), 0, stream, fc, ba,
+                           fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(),
+                           fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), ctr, count_blocks);
     }
-    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[3], stream));
+    HIP_TRY(hipEventRecord(fs->ev[3], stream));
 
-    // ---- binning (the count of the primitives' own tiles happened in k_tri_setup / k_quad_setup):
-    // count of the large primitives' work items, scan, fill
-    const unsigned list_blocks = blocks_for(std::max<long long>(fc.n_faces, n_tiles), 256);
-    const unsigned large_blocks = 512;       // grid-stride over the work items, 4 wavefronts per block
-    // one wavefront per face whose survivor count is still open, grid-stride; up to 512 workgroups: a mesh of
-    // large faces lists most of them (c2/c3: 128 -> 512 workgroups took 3 us off)
-    const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
-    hipLaunchKernelGGL(k_bin_large_and_count, dim3(count_blocks + large_blocks), dim3(256), 0, stream, fc, ba,
-                       fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                       fs->d_status.as<uint8_t>(), ctr, count_blocks);
-    if (all_marks) HIP_TRY(hipEventRecord(fs->ev[4], stream));
-    hipLaunchKernelGGL(k_scan_bins, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, stream, fs->d_bin_count.as<uint32_t>(),
-                       fs->d_bin_offset.as<uint32_t>(), n_tiles, fs->item_cap, ctr,
-                       fs->d_scan_part.as<unsigned long long>(), (uint32_t)(fs->frames_enqueued % 0xfffffffeull) + 1u);
-    hipLaunchKernelGGL(k_bin_fill, dim3(list_blocks + large_blocks), dim3(256), 0, stream, fc, ba, large_blocks);
-    HIP_TRY(hipEventRecord(fs->ev[5], stream));
-
-    // ---- visibility: coverage, z, winner; then the shadow volumes' stencil counts
-    hipLaunchKernelGGL(k_tile_raster, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc,
-                       fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                       fs->d_bin_offset.as<uint32_t>(), fs->d_items.as<uint32_t>(), fs->item_cap,
-                       fs->d_bin_count.as<uint32_t>(), fs->d_z.as<double>(), fs->d_winner.as<int32_t>(),
-                       fs->d_stencil.as<int32_t>(), fs->d_tile_stats.as<uint32_t>());
-    HIP_TRY(hipEventRecord(fs->ev[6], stream));
-    // grid-stride over the work items; 4096 workgroups (16 per CU) keep every CU's 6-8 slots refilled
-    if (shadows)
-        hipLaunchKernelGGL(k_tile_quads, dim3(4096), dim3(TILE_PX), 0, stream, fc, fs->d_quads.as<QuadRec>(),
-                           fs->d_quad_work.as<uint4>(), fs->quad_work_cap, fs->d_items.as<uint32_t>(), fs->item_cap,
-                           fs->d_z.as<double>(), fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(),
-                           fs->d_tile_stats.as<uint32_t>(), ctr);
-    HIP_TRY(hipEventRecord(fs->ev[7], stream));
+    // ---- 3. tiles: coverage, z, stencil, shading, finalise
+    TileArgs ta;
+    ta.clips = fs->d_clips.as<TriClip>(); ta.quads = fs->d_quads.as<QuadRec>();
+    ta.bin_count = fs->d_bin_count.as<uint32_t>();
+    for (int c = 0; c < BIN_CLASSES; ++c) { ta.items[c] = fs->d_items[c].as<uint32_t>(); ta.cap[c] = fs->bin_cap[c]; }
+    ta.zbuf = keep ? fs->d_z.as<double>() : nullptr;
+    ta.winner = keep ? fs->d_winner.as<int32_t>() : nullptr;
+    ta.stencil = keep ? fs->d_stencil.as<int32_t>() : nullptr;
+    ta.tile_stats = fs->d_tile_stats.as<uint32_t>();
+    ta.ctr = ctr; ta.next_ctr = next_ctr;
+    ta.hist = hist; ta.next_hist = next_hist;
+    ta.heavy_flag = fs->d_heavy_flag.as<uint8_t>() + (size_t)par * std::max(n_tiles, 1);
+    ta.next_heavy_flag = fs->d_heavy_flag.as<uint8_t>() + (size_t)(par ^ 1u) * std::max(n_tiles, 1);
+    ShadeArgs sh;
+    sh.tris = fs->d_tris.as<TriRec>(); sh.attrs = fs->d_attrs.as<TriAttr>();
+    sh.materials = sc->d_materials.as<Material>();
+    sh.sky = sc->sky_size > 0 ? sc->d_sky.as<uint8_t>() : nullptr;
+    sh.gamma_lut = sc->d_gamma.as<float>();
+    sh.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
+    sh.out = d_out;
+    if (n_tiles > 0)
+        hipLaunchKernelGGL(k_tile, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
+    else          // nothing to draw on this device (a stripe beyond the frame): still hand the counters on
+        HIP_TRY(hipMemsetAsync(next_ctr, 0, sizeof(Counters), stream));
+    HIP_TRY(hipEventRecord(fs->ev[4], stream));
     if ((fc.flags & MR_FRAME_FACE_STATUS) && fc.n_faces > 0)
         hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
-                           fs->d_valid.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
-                           fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>(), ctr);
-
-    // ---- deferred shading + finalise
-    ShadeArgs sa;
-    sa.tris = fs->d_tris.as<TriRec>(); sa.clips = fs->d_clips.as<TriClip>(); sa.faces = sc->d_faces.as<int32_t>();
-    sa.face_flags = sc->d_face_flags.as<uint8_t>(); sa.verts = sc->d_verts.as<double>();
-    sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
-    sa.materials = sc->d_materials.as<Material>(); sa.textures = sc->d_textures.as<Texture>();
-    sa.winner = fs->d_winner.as<int32_t>(); sa.stencil = fs->d_stencil.as<int32_t>();
-    sa.sky = sc->sky_size > 0 ? sc->d_sky.as<uint8_t>() : nullptr;
-    sa.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
-    sa.gamma_lut = sc->d_gamma.as<float>();
-    sa.out = d_out;
-    hipLaunchKernelGGL(k_shade, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc, sa);
-    HIP_TRY(hipEventRecord(fs->ev[8], stream));
+                           fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(), fs->d_clips.as<TriClip>(),
+                           fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>());
     HIP_TRY(hipGetLastError());
     fs->last_frame = *fr;
+    fs->last_frame.flags = fc.flags;
     fs->last_n_tiles = n_tiles;
     fs->have_frame = true;
     fs->stats_reduced = false;
@@ -490,16 +544,16 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     return MR_OK;
 }
 
-// The fragment / pixel counts of a frame are left as per-tile partials by the visibility
-// kernels; they are summed and fetched only when somebody asks (mr_render, mr_get_stats).
+// The fragment / pixel counts of a frame are left as per-tile partials by the tile kernel; they
+// are summed and fetched only when somebody asks (mr_render, mr_get_stats).
 int fetch_counters(mr_scene *sc, FrameSlot *fs)
 {
     using namespace mr;
-    Counters *ctr = fs->d_counters.as<Counters>();
-    if (!fs->stats_reduced && (fs->last_frame.flags & MR_FRAME_COUNTERS)) {
-        const FrameConst fc = make_const(sc, &fs->last_frame);
-        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(512), dim3(256), 0, fs->stream, fc, fs->d_tile_stats.as<uint32_t>(),
-                           fs->last_n_tiles, fs->d_winner.as<int32_t>(), fs->d_stencil.as<int32_t>(), ctr);
+    (void)sc;
+    Counters *ctr = fs->ctr(fs->frames_enqueued - 1);
+    if (!fs->stats_reduced && fs->last_n_tiles > 0) {
+        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(256), dim3(256), 0, fs->stream, fs->d_tile_stats.as<uint32_t>(),
+                           fs->last_n_tiles, ctr);
         fs->stats_reduced = true;
     }
     HIP_TRY(hipMemcpyAsync(fs->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, fs->stream));
@@ -525,20 +579,24 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
     float ms = 0;
     auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, fs->ev[a], fs->ev[b]); return ms; };
     const bool light = (fs->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
-    s.gpu_ms_geometry = light ? 0.f : span(0, 3); s.gpu_ms_binning = light ? 0.f : span(3, 5);
-    s.gpu_ms_raster = span(5, 7); s.gpu_ms_shade = span(7, 8);
-    s.gpu_ms_copy = with_copy ? span(8, 9) : 0.f;
-    s.gpu_ms_total = span(0, with_copy ? 9 : 8);
+    s.gpu_ms_setup = light ? 0.f : span(0, 2); s.gpu_ms_binning = light ? span(0, 3) : span(2, 3);
+    s.gpu_ms_tile = span(3, 4);
+    s.gpu_ms_copy = with_copy ? span(4, 5) : 0.f;
+    s.gpu_ms_total = span(0, with_copy ? 5 : 4);
     bool grown = false;
     if (c.overflow) {
-        const uint32_t entries = c.bin_total;
-        if (c.overflow & 1u) fs->item_cap = entries + entries / 2 + 1024;
-        if (c.overflow & 2u) fs->work_cap = c.n_work + c.n_work / 2 + 1024;
-        if (c.overflow & 4u) fs->quad_cap = std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, fs->quad_cap * 2);
-        if (c.overflow & 8u) fs->quad_work_cap = c.n_quad_work + c.n_quad_work / 2 + 1024;
+        for (int cls = 0; cls < mr::BIN_CLASSES; ++cls)
+            if (c.overflow & (1u << cls)) {
+                uint32_t want = std::max(c.max_list[cls] + c.max_list[cls] / 2, fs->bin_cap[cls] * 2);
+                uint32_t cap = 64;
+                while (cap < want) cap <<= 1;
+                sc->bin_cap[cls] = std::max(sc->bin_cap[cls], cap);
+            }
+        if (c.overflow & 8u) sc->work_cap = std::max(sc->work_cap, c.n_work + c.n_work / 2 + 1024);
+        if (c.overflow & 16u) sc->quad_cap = std::max(sc->quad_cap, std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, fs->quad_cap * 2));
         grown = true;
     }
-    if (c.n_quads > fs->quad_cap) { fs->quad_cap = c.n_quads + c.n_quads / 2 + 64; grown = true; }
+    if (c.n_quads > fs->quad_cap) { sc->quad_cap = std::max(sc->quad_cap, c.n_quads + c.n_quads / 2 + 64); grown = true; }
     return grown ? MR_E_OVERFLOW : MR_OK;
 }
 
@@ -611,10 +669,23 @@ int mr_scene_clear(mr_scene *sc)
     for (void *p : sc->texture_allocs) (void)hipFree(p);
     sc->texture_allocs.clear(); sc->textures.clear();
     sc->verts.clear(); sc->uv.clear(); sc->normals.clear(); sc->faces.clear(); sc->face_flags.clear();
-    sc->materials.clear(); sc->models.clear(); sc->edge_offset.clear(); sc->edge_inc.clear();
+    sc->materials.clear(); sc->models.clear(); sc->edges.clear(); sc->edge_inc.clear();
+    sc->edge_ids.clear(); sc->edge_raw.clear();
     sc->dirty = true;
     sc->last = nullptr;
+    sc->reset_caps();
     for (auto &fs : sc->slots) fs->reset_caps();
+    return MR_OK;
+}
+
+int mr_scene_set_list_capacities(mr_scene *sc, uint32_t small_pairs, uint32_t big_pairs, uint32_t quads, uint32_t work)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    if (g_initialised) (void)hipDeviceSynchronize();
+    if (small_pairs) sc->bin_cap[0] = small_pairs;
+    if (big_pairs) sc->bin_cap[1] = big_pairs;
+    if (quads) sc->bin_cap[2] = quads;
+    if (work) sc->work_cap = work;
     return MR_OK;
 }
 
@@ -623,7 +694,7 @@ void mr_scene_destroy(mr_scene *sc)
     if (!sc) return;
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
-                       &sc->d_textures, &sc->d_edge_offset, &sc->d_edge_inc, &sc->d_sky, &sc->d_gamma };
+                       &sc->d_textures, &sc->d_edges, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();
     delete sc;
@@ -692,6 +763,8 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
         if (m->uv && (c[1] < 0 || c[1] >= m->n_uv)) return fail(MR_E_INVALID, "uv index out of range");
         if (m->normals && (c[2] < 0 || c[2] >= m->n_normals)) return fail(MR_E_INVALID, "normal index out of range");
         if (c[3] < 0 || c[3] >= m->n_materials) return fail(MR_E_INVALID, "material index out of range");
+        if (m->edge_ids && (m->edge_ids[i] < -m->n_vertices || m->edge_ids[i] >= m->n_vertices))
+            return fail(MR_E_INVALID, "edge id out of range");
     }
     if (g_initialised) (void)hipDeviceSynchronize();     // frames in flight still use the old scene
     sc->verts.insert(sc->verts.end(), m->vertices, m->vertices + (size_t)m->n_vertices * 4);
@@ -716,9 +789,17 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
         sc->faces.push_back(c[3] + mi.mat_off);
     }
     sc->face_flags.insert(sc->face_flags.end(), (size_t)m->n_faces, ff);
+    // silhouette edges are matched on the corners' RAW vertex ids (see mr_model_desc.edge_ids): raw values
+    // lie in [-n_vertices, n_vertices); shifted by n_vertices + 2 * vert_off they are unique per model
+    for (int64_t i = 0; i < (int64_t)m->n_faces * 3; ++i) {
+        const int32_t raw = m->edge_ids ? m->edge_ids[i] : m->faces[i * 4];
+        sc->edge_raw.push_back(raw);
+        sc->edge_ids.push_back(raw + m->n_vertices + 2 * mi.vert_off);
+    }
     sc->models.push_back(mi);
     sc->dirty = true;
     sc->last = nullptr;
+    sc->quad_cap = 0;
     for (auto &fs : sc->slots) fs->reset_caps();
     return (int)sc->models.size() - 1;
 }
@@ -734,13 +815,13 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     mr_frame_desc counted = *fr;
     if (stats) counted.flags |= MR_FRAME_COUNTERS;         // whoever asks for the counters gets them
     fr = &counted;
-    const size_t band_bytes = (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
+    const size_t band_bytes = out_bytes(fr);
     for (int attempt = 0; attempt < 6; ++attempt) {
         HIP_TRY(fs->d_out.ensure(band_bytes));
         if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
         if ((rc = fetch_counters(sc, fs))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipEventRecord(fs->ev[9], g_stream));
+        HIP_TRY(hipEventRecord(fs->ev[5], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         rc = collect(sc, fs, true);
         if (rc == MR_OK) {
@@ -798,7 +879,8 @@ int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
     const mr_frame_desc &ref = sc->last->last_frame;
     auto same_kind = [&](const FrameSlot &s) {
         return s.have_frame && s.last_frame.flags == ref.flags && s.last_frame.row_begin == ref.row_begin &&
-               s.last_frame.row_end == ref.row_end;
+               s.last_frame.row_end == ref.row_end && s.last_frame.stripe_count == ref.stripe_count &&
+               s.last_frame.stripe_index == ref.stripe_index;
     };
     int active = 0;
     for (auto &s : sc->slots) active += same_kind(*s) ? 1 : 0;
@@ -809,13 +891,14 @@ int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
         const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(s->frames_enqueued, EVENT_RING), per_slot);
         for (uint64_t i = 0; i < n; ++i) {
             hipEvent_t *ev = s->ev_ring[(s->frames_enqueued - 1 - i) % EVENT_RING];
-            float ms;
-            for (int k = light ? 5 : 0; k < 8; ++k) {
-                ms = 0; (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
-                acc[k] += ms;
+            auto span = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return (double)ms; };
+            if (light) {
+                acc[2] += span(0, 3);
+            } else {
+                acc[0] += span(0, 1); acc[1] += span(1, 2); acc[2] += span(2, 3);
             }
-            ms = 0; (void)hipEventElapsedTime(&ms, ev[0], ev[8]);
-            acc[8] += ms;
+            acc[3] += span(3, 4);
+            acc[4] += span(0, 4);
         }
         used += n;
     }
@@ -827,6 +910,8 @@ int mr_read_z(mr_scene *sc, double *out)
 {
     FrameSlot *fs = last_slot(sc);
     if (!fs) return MR_E_INVALID;
+    if (!(fs->last_frame.flags & MR_FRAME_KEEP_BUFFERS))
+        return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_KEEP_BUFFERS");
     return read_back(fs->d_z, out, (size_t)fs->last_frame.width * fs->last_frame.height, "z");
 }
 
@@ -834,6 +919,8 @@ int mr_read_stencil(mr_scene *sc, int16_t *out)
 {
     FrameSlot *fs = last_slot(sc);
     if (!fs) return MR_E_INVALID;
+    if (!(fs->last_frame.flags & MR_FRAME_KEEP_BUFFERS))
+        return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_KEEP_BUFFERS");
     const size_t n = (size_t)fs->last_frame.width * fs->last_frame.height;
     std::vector<int32_t> wide(n);           // the device accumulates in 32 bits; the reference's buffer is int16
     int rc = read_back(fs->d_stencil, wide.data(), n, "stencil");
@@ -847,6 +934,8 @@ int mr_read_winner(mr_scene *sc, int32_t *out)
 {
     FrameSlot *fs = last_slot(sc);
     if (!fs) return MR_E_INVALID;
+    if (!(fs->last_frame.flags & MR_FRAME_KEEP_BUFFERS))
+        return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_KEEP_BUFFERS");
     return read_back(fs->d_winner, out, (size_t)fs->last_frame.width * fs->last_frame.height, "winner");
 }
 
@@ -865,8 +954,8 @@ int mr_read_face_status(mr_scene *sc, uint8_t *out)
     if (!fs) return MR_E_INVALID;
     if (!(fs->last_frame.flags & MR_FRAME_FACE_STATUS))
         return fail(MR_E_INVALID, "the last frame was rendered without MR_FRAME_FACE_STATUS");
-    if (fs->last_frame.row_begin != 0 || fs->last_frame.row_end != fs->last_frame.height)
-        return fail(MR_E_INVALID, "per-face status needs the whole frame on one device (no row band)");
+    if (fs->last_frame.row_begin != 0 || fs->last_frame.row_end != fs->last_frame.height || fs->last_frame.stripe_count > 1)
+        return fail(MR_E_INVALID, "per-face status needs the whole frame on one device (no row band, no stripes)");
     return read_back(fs->d_status, out, sc->faces.size() / 12, "face status");
 }
 
@@ -877,6 +966,7 @@ int mr_debug_read_tile_records(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
     if (!out) return fail(MR_E_INVALID, "NULL argument");
     const int n = std::min(fs->last_n_tiles, cap_tiles);
     HIP_TRY(hipDeviceSynchronize());
+    static_assert(mr::TILE_REC == MR_TILE_RECORD_WORDS, "tile record size is part of the ABI");
     if (n > 0) HIP_TRY(hipMemcpy(out, fs->d_tile_stats.p, (size_t)n * mr::TILE_REC * 4, hipMemcpyDeviceToHost));
     return fs->last_n_tiles;
 }
@@ -888,16 +978,16 @@ int mr_read_silhouette(mr_scene *sc, int32_t *out, int32_t cap)
     const int n = sc->n_silhouette;
     const int take = std::min(std::min(n, cap), (int)fs->quad_cap);
     if (take > 0 && out) {
-        std::vector<int32_t> raw((size_t)take * 3);
+        std::vector<int32_t> raw((size_t)take * 2);
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(raw.data(), fs->d_sil.p, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (int i = 0; i < take; ++i) {
-            const int face = raw[i * 3];
+            const int face = raw[i * 2], k = raw[i * 2 + 1];
             int model = 0;
             while (model + 1 < (int)sc->models.size() && face >= sc->models[model + 1].face_off) ++model;
-            out[i * 3 + 0] = model;
-            out[i * 3 + 1] = raw[i * 3 + 1] - sc->models[model].vert_off;
-            out[i * 3 + 2] = raw[i * 3 + 2] - sc->models[model].vert_off;
+            out[i * 3 + 0] = model;                              // entries of model.silhouette carry the raw ids
+            out[i * 3 + 1] = sc->edge_raw[(size_t)face * 3 + k];
+            out[i * 3 + 2] = sc->edge_raw[(size_t)face * 3 + (k + 1) % 3];
         }
     }
     return n;

@@ -2,7 +2,8 @@
 //
 // Vocabulary follows the reference renderer: faces (triangles), silhouette edges, shadow
 // quads, fragments, z / stencil / frame buffers.  A "tile" is the block of TILE_W x TILE_H
-// pixels owned by one workgroup of the visibility kernel, which keeps the tile's z-buffer in LDS.
+// pixels owned by one workgroup of the tile kernel, which keeps the tile's z-buffer, winner map
+// and stencil counts on chip from the first triangle to the finished uint8 pixels.
 #pragma once
 
 #include <stdint.h>
@@ -11,10 +12,10 @@ namespace mr {
 
 constexpr int TILE_W = 16;
 constexpr int TILE_H = 16;
-constexpr int TILE_PX = TILE_W * TILE_H;    // one thread per pixel in the visibility kernel
+constexpr int TILE_PX = TILE_W * TILE_H;    // one thread per pixel in the tile kernel
 constexpr int WAVE = 64;
 // A (triangle, tile) pair whose pixel box inside the tile holds more samples than this is
-// evaluated one pixel per thread ("big" pair); smaller ones one triangle per thread.
+// evaluated one pixel per thread ("big" pair); smaller ones a few lanes per triangle.
 constexpr int BIG_PAIR_PX = 24;
 constexpr int BIN_CLASSES = 3;              // small triangle pairs, big triangle pairs, shadow quads
 
@@ -29,7 +30,7 @@ enum : uint8_t {
 // per-face flags copied from the owning Model
 enum : uint8_t { FF_CLIP = 1, FF_VERTS_F32 = 2, FF_HAS_NORMALS = 4, FF_HAS_UV = 8 };
 
-// TriRec.flags
+// TriRec.flags (bits 8-15 carry the face flags above)
 enum : uint32_t {
     TF_CLIP = 1,          // Model.clip: per-fragment frustum test against both cameras
     TF_SINGLE_BOX = 2,    // pixel box holds exactly one sample  -> NumPy's (1,K)@(K,) is a dot
@@ -44,9 +45,11 @@ struct FrameConst {
     int32_t light_type;
     int32_t flags;
     int32_t band_y0, band_y1;    // screen rows [band_y0, band_y1) this device owns (y up, unflipped)
-    int32_t tiles_x, tiles_y;    // tile grid of the band
-    int32_t tile_y0;             // first tile row of the band (in full-frame tile rows)
-    int32_t n_vertices, n_faces, n_edges;
+    int32_t tiles_x, tiles_y;    // tile grid this device owns: tiles_y local tile rows
+    int32_t tile_y0, tile_step;  // local tile row l is frame tile row tile_y0 + l * tile_step
+    int32_t out_tile_rows;       // > 0: striped output layout with this many tile rows per device (see out_row)
+    int32_t n_vertices, n_faces, n_edges, n_materials;
+    int32_t same_clip;           // debug_mvp == mvp bit for bit: the second clip test repeats the first
     double mvp[16], viewport[16], debug_mvp[16];
     double planes[24];
     double two_nf, f_plus_n, f_minus_n;      // linearize_z constants (obj/core.py:226-228)
@@ -58,17 +61,16 @@ struct FrameConst {
     uint32_t background_u8;      // finalised background r | g << 8 | b << 16 | 1 << 24 (0 = not given)
     int32_t sky_tri[12];         // skybox triangles' integer screen vertices [t][v][xy]
     int32_t sky_size;            // cubemap face size
-    int32_t same_clip;           // debug_mvp == mvp bit for bit: the second clip test repeats the first
+    int32_t pad0;
     double sky_rays[18];         // their un-projected corner rays [t][v][xyz]
 };
 
-// Output of the vertex kernel: everything obj/triangular.py:36-45 derives per face corner,
-// computed once per unique vertex.  The clip-space coordinates go to a side array: a face whose
-// three vertices are flagged `safe` never reads them.
+// Output of the optional stand-alone vertex kernel (k_vertex_mfma): everything
+// obj/triangular.py:36-45 derives per face corner, once per unique vertex.
 struct alignas(16) VertexOut {
     double sx, sy, sz, depth;    // screen x, y, z and 1/clip.w
     double zlin;                 // linearize_z(sz)
-    int32_t safe;                // strictly inside both clip volumes with margin (see k_vertex)
+    int32_t safe;                // strictly inside both clip volumes with margin (see xform_vertex)
     int32_t pad;
 };
 static_assert(sizeof(VertexOut) == 48, "VertexOut layout");
@@ -77,7 +79,7 @@ struct alignas(16) VertexClip {
     double clipd[4];             // v @ debug_camera.MVP
 };
 
-// Triangle set-up record walked by the visibility kernel: the per-face constants of
+// Triangle set-up record walked by the tile kernel: the per-face constants of
 // obj/transformation.py:12-32 and obj/triangular.py:96-97.  112 bytes = 7 x 16 so a lane can
 // fetch a whole record with seven 16-byte loads.
 struct alignas(16) TriRec {
@@ -88,15 +90,26 @@ struct alignas(16) TriRec {
     int16_t x0, x1, y0, y1;      // half-open pixel box
     uint32_t flags;
     int32_t face;                // global face index
-    uint32_t pad[2];
+    int32_t material;            // global material index of the face (first corner's group, obj/core.py:125)
+    uint32_t pad;
 };
 static_assert(sizeof(TriRec) == 112, "TriRec layout");
 
-// The rest of a face's set-up: 1/w of the corners (perspective-correct barycentrics,
-// obj/core.py:155-160) and, for models with clip=True, both cameras' clip-space corners.
+// What shading needs of a face, gathered ONCE per frame by the set-up kernel (which has the
+// corners in registers anyway) instead of once per pixel through the index row: 1/w of the
+// corners (perspective-correct barycentrics, obj/core.py:155-160), world-space corners, uv and
+// vertex normals.  176 bytes = 11 x 16.
+struct alignas(16) TriAttr {
+    double dp[3];                // 1 / clip.w per corner
+    double world[3][3];          // world xyz per corner
+    float uv[3][2];
+    float n[3][3];
+    float pad[3];
+};
+static_assert(sizeof(TriAttr) == 176, "TriAttr layout");
+
+// Both cameras' clip-space corners; written only for faces whose fragments need the clip test.
 struct alignas(16) TriClip {
-    double dp[3];
-    double pad;
     double clip[3][4];
     double clipd[3][4];
 };
@@ -108,11 +121,22 @@ struct alignas(16) QuadRec {
     int16_t x0, x1, y0, y1;      // half-open pixel box
     int32_t n;                   // vertex count (>= 3)
     int32_t is_front;
-    int32_t edge;                // unique-edge index it came from
+    int32_t edge;                // silhouette-list entry it came from
     uint32_t pad[3];
     QuadEdge e[MAX_POLY];
 };
 static_assert(sizeof(QuadRec) == 64 + 32 * MAX_POLY, "QuadRec layout");
+
+// Static per unique undirected edge (built when the scene is committed): its first two incident
+// (face, corner) pairs in face order with those faces' unit normals inline -- the light-facing
+// test of obj/triangular.py:294-295 is normal . light.position > 0 and the normal does not
+// depend on the frame -- and, for the rare edge with more incidences, a range of the spill array.
+struct alignas(16) EdgeRec {
+    uint32_t inc[2];             // face * 4 + corner, 0xffffffff = none
+    uint32_t extra_off, extra_cnt;
+    double n[2][3];
+};
+static_assert(sizeof(EdgeRec) == 64, "EdgeRec layout");
 
 struct Texture {
     const float *rgb;
@@ -129,17 +153,20 @@ struct Material {
     Texture map_kd, map_norm, map_ks;
 };
 
-// Device-side counters of one frame; copied back once at the end.
-struct Counters {
+// Device-side counters of one frame; copied back when somebody asks.  The words that many
+// wavefronts add to during a frame sit on cache lines of their own: atomics to one line retire
+// at ~0.3 per ns on MI355X whatever the address in it (tools/micro/atomic_bench.hip).
+struct alignas(128) Counters {
     unsigned long long frag_tri, frag_quad, covered_px, lit_px, stencil_updates;
-    unsigned int n_valid_tris, n_quads, n_quads_drawn;
-    unsigned int n_count;        // faces whose survivor count is left to k_tri_count
-    unsigned int pad2;
-    unsigned int tri_bin_total, bin_total;     // items of the two triangle classes; of all three
-    unsigned int n_work;         // (large primitive, 64-tile chunk) work items of the binning pass
-    unsigned int n_quad_work;    // (tile, quad batch) work items of the stencil pass
-    unsigned int overflow;       // bit0: bin items, bit1: binning work list, bit2: quad list, bit3: quad work list
-    unsigned int pad;
+    unsigned int n_valid_tris, tri_bin_total, bin_total;
+    unsigned int overflow;       // bit0-2: a tile's small / big / quad list, bit3: work list, bit4: quad list
+    unsigned int max_list[BIN_CLASSES];       // longest list seen by an overflowing tile, per class
+    unsigned int pad0[15];
+    unsigned int n_quads;        unsigned int pad1[31];     // silhouette edges
+    unsigned int n_quads_drawn;  unsigned int pad2[31];     // quads that got a record
+    unsigned int n_count;        unsigned int pad3[31];     // faces whose survivor count is left to k_bin_work
+    unsigned int n_work;         unsigned int pad4[31];     // (large primitive, 64-tile chunk) work items
 };
+static_assert(sizeof(Counters) == 128 * 5, "Counters layout");
 
 }  // namespace mr

@@ -2,13 +2,21 @@
 
 The path shards by pixels: every mutable buffer of the reference (frame, z, stencil) is
 per-pixel and primitives interact only through them (obj/triangular.py:101-118,356-368), so
-disjoint row bands are independent.  Geometry, textures and per-frame constants are replicated;
-each rank rasterises and shades only its band of H/world output rows and ONE all-gather (RCCL
-over xGMI when the backend is "nccl") assembles the uint8 frame on every rank.  Row bands in
-output order make the gathered buffer the final frame with no reorder.
+disjoint sets of screen tiles are independent.  Geometry, textures and per-frame constants are
+replicated; each rank rasterises and shades only its tiles and ONE all-gather (RCCL over xGMI
+when the backend is "nccl") assembles the uint8 frame on every rank.  Two partitions:
+
+* ``"bands"``   rank r renders the contiguous band of H/world output rows; bands in output order
+  make the gathered buffer the final frame with no reorder, but the load is uneven (sky bands are
+  empty, the band holding the mesh and its shadow is the whole frame's critical path);
+* ``"stripes"`` rank r renders the tile rows (16 screen rows) t with t mod world == r -- every rank
+  gets an interleaved sample of the screen, so the load is balanced -- and one row gather
+  (``unstripe``) after the all-gather puts the rows in frame order.
 """
 import torch
 import torch.distributed as dist
+
+TILE_ROWS = 16
 
 
 def row_band(height, rank, world):
@@ -21,11 +29,43 @@ def row_band(height, rank, world):
     return rank * rows, (rank + 1) * rows
 
 
-def all_gather_frame(part, frame=None, group=None):
-    """Assemble the frame from every rank's band with a single collective.
+def stripe_rows(height, world):
+    """Rows of one rank's output buffer in the striped layout: its share of the frame's tile rows,
+    rounded up so that every rank sends the same amount (``mr_frame_desc.stripe_count``)."""
+    tile_rows = -(-int(height) // TILE_ROWS)
+    return -(-tile_rows // int(world)) * TILE_ROWS
 
-    *part* is this rank's ``(rows, W, 3)`` uint8 band (any device); returns ``(rows*world, W, 3)``.
-    """
+
+def unstripe_index(height, world, device=None):
+    """For every output row of the frame, its row in the all-gathered striped buffer.
+
+    Rank r holds the frame's tile rows g = r, r + world, ... (counted from the BOTTOM of the frame,
+    like the reference's buffers), highest first, rows inside a tile row top-down
+    (``include/mi355rast.h``, stripe_count)."""
+    per = stripe_rows(height, world)
+    out_row = torch.arange(height, dtype=torch.long)
+    py = height - 1 - out_row                               # screen row, y up
+    g = py // TILE_ROWS
+    rank, local = g % world, g // world
+    idx = rank * per + (per // TILE_ROWS - 1 - local) * TILE_ROWS + (TILE_ROWS * g + TILE_ROWS - 1 - py)
+    return idx.to(device) if device is not None else idx
+
+
+def unstripe(gathered, height, world, out=None, index=None):
+    """Frame ``(height, W, 3)`` from the all-gathered striped buffer ``(world * stripe_rows, W, 3)``."""
+    if index is None:
+        index = unstripe_index(height, world, gathered.device)
+    if out is None:
+        return gathered.index_select(0, index)
+    torch.index_select(gathered, 0, index, out=out)
+    return out
+
+
+def all_gather_frame(part, frame=None, group=None):
+    """Assemble every rank's rows with a single collective.
+
+    *part* is this rank's ``(rows, W, 3)`` uint8 buffer (any device); returns ``(rows*world, W, 3)``:
+    the frame itself for row bands, the striped buffer (see ``unstripe``) for stripes."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if frame is None:
         frame = torch.empty((part.shape[0] * world,) + tuple(part.shape[1:]), dtype=part.dtype,
@@ -39,45 +79,88 @@ def all_gather_frame(part, frame=None, group=None):
 
 
 class BandRenderer:
-    """Per-rank driver: render this rank's band into HBM, then all-gather the frame.
+    """Per-rank driver: render this rank's tiles into HBM, then all-gather the frame.
 
     ``frames_in_flight`` > 1 renders successive frames on different HIP streams (each with
     its own output buffers and its own work buffers inside the library), so the short,
     latency-bound stages of one frame overlap with the next frame's: throughput mode.  With 1
     every frame runs alone on one stream: latency mode.
+
+    Frames are enqueued without host synchronisation, so a work list that overflows cannot be
+    retried on the spot the way ``mr_render`` does it: the priming frames are checked here (and
+    rendered again with the grown lists), and ``verify()`` does the same for the frames since.
     """
 
-    def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False, frames_in_flight=1):
+    def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False, frames_in_flight=1,
+                 partition="bands"):
         height, width = (int(v) for v in scene.resolution)
-        self.rank, self.world = rank, world
-        self.band = row_band(height, rank, world)
+        if partition not in ("bands", "stripes"):
+            raise ValueError(f"unknown partition {partition!r}")
+        self.rank, self.world, self.partition = rank, world, partition
+        self.height, self.width = height, width
         self.backend = scene._backend()
-        rows = self.band[1] - self.band[0]
+        self.scene, self.shadows, self.light_timing = scene, shadows, light_timing
+        striped = partition == "stripes" and world > 1
+        self.stripe = (rank, world) if striped else None
+        self.band = (0, height) if striped else row_band(height, rank, world)
+        rows = stripe_rows(height, world) if striped else self.band[1] - self.band[0]
         self.lanes = []
         self.count = 0
-        self.desc = None
+        self.descs = []
         for _ in range(max(1, int(frames_in_flight))):
             stream = torch.cuda.Stream()
             frame = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
             part = frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
-            with torch.cuda.stream(stream):
-                self.desc = self.backend.render_device(scene, part.data_ptr(), stream.cuda_stream, shadows=shadows,
-                                                       row_band=self.band, light_timing=light_timing)
-            stream.synchronize()
-            self.lanes.append((stream, frame, part))
+            gathered = torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda") if striped else frame
+            self.lanes.append((stream, frame, part, gathered))
+        self.index = unstripe_index(height, world, "cuda") if striped else None
+        self.desc = None
+        self.prime()
         self.frame = self.lanes[0][1]
+
+    def prime(self):
+        """One frame per lane through the full host path (scene sync, frame packing); repeated while
+        a work list overflows, so that the frames enqueued afterwards find lists that are large enough."""
+        for _ in range(6):
+            for stream, _, part, _ in self.lanes:
+                with torch.cuda.stream(stream):
+                    self.desc = self.backend.render_device(self.scene, part.data_ptr(), stream.cuda_stream,
+                                                           shadows=self.shadows, row_band=self.band,
+                                                           light_timing=self.light_timing, stripe=self.stripe)
+                stream.synchronize()
+            if not self.backend.overflowed():
+                return
+        raise RuntimeError("work lists kept overflowing while priming")
+
+    def set_descriptors(self, descs):
+        """Frame descriptors to cycle through in ``step`` (e.g. a camera path), instead of repeating
+        the priming frame's."""
+        self.descs = list(descs)
 
     def step(self):
         """Enqueue one frame (no host synchronisation); returns the tensor it will land in."""
-        stream, frame, part = self.lanes[self.count % len(self.lanes)]
+        stream, frame, part, gathered = self.lanes[self.count % len(self.lanes)]
+        desc = self.descs[self.count % len(self.descs)] if self.descs else self.desc
         self.count += 1
         with torch.cuda.stream(stream):
-            self.backend.enqueue(self.desc, part.data_ptr(), stream.cuda_stream)
+            self.backend.enqueue(desc, part.data_ptr(), stream.cuda_stream)
             if self.world > 1:
-                all_gather_frame(part, frame)
+                all_gather_frame(part, gathered)
+                if self.index is not None:
+                    unstripe(gathered, self.height, self.world, out=frame, index=self.index)
         self.frame = frame
         return frame
 
+    def verify(self):
+        """Synchronise and check that no frame since the last check overflowed a work list.  Returns
+        True when all was well; otherwise the lists have been grown, the lanes primed again, and the
+        frames enqueued since the last check must be considered invalid."""
+        self.synchronize()
+        if not self.backend.overflowed():
+            return True
+        self.prime()
+        return False
+
     def synchronize(self):
-        for stream, _, _ in self.lanes:
+        for stream, *_ in self.lanes:
             stream.synchronize()

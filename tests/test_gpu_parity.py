@@ -79,7 +79,7 @@ def test_frame_only_mode_renders_the_same_frame(api, name):
     exact = backend.render(scene, shadows=shadows, keep_float=True, counters=True)
     z, winner, stencil, frame = backend.read_z(), backend.read_winner(), backend.read_stencil(), backend.read_frame_f32()
     assert backend.last_stats["frag_tri"] > 0
-    fast = backend.render(scene, shadows=shadows, keep_float=True, counters=False)
+    fast = backend.render(scene, shadows=shadows, keep_float=True, counters=False, keep_buffers=True)
     assert np.array_equal(fast, exact)
     assert np.array_equal(backend.read_z().view(np.uint64), z.view(np.uint64))
     assert np.array_equal(backend.read_winner(), winner)
@@ -118,6 +118,51 @@ def test_row_bands_tile_the_frame(api, bands):
     scene.close()
 
 
+@pytest.mark.parametrize("name,world", [("diablo_floor_small", 2), ("diablo_floor_small", 3), ("diablo_floor_small", 8),
+                                        ("tetra_ortho", 5), ("c4_torus200k_1080p", 8), ("c3_diablo_floor_1080p", 4)])
+def test_tile_row_stripes_tile_the_frame(api, name, world):
+    """Screen-tile split, interleaved: rendering every rank's tile rows (t mod world == rank) into the
+    striped layout, concatenating them the way the all-gather does and un-permuting gives the whole
+    frame (what the multi-GPU path does with partition="stripes")."""
+    import torch
+    from py_numpy_renderer_amd.multigpu import stripe_rows, unstripe
+    scene = scenes.build(api, name)
+    backend = scene._backend()
+    full = scene.render()
+    h = full.shape[0]
+    parts = [backend.render(scene, counters=False, stripe=(r, world)) for r in range(world)]
+    assert all(p.shape[0] == stripe_rows(h, world) for p in parts)
+    frame = unstripe(torch.from_numpy(np.concatenate(parts, axis=0)), h, world).numpy()
+    assert np.array_equal(frame, full)
+    scene.close()
+
+
+def test_work_lists_grow_on_overflow(api):
+    """Per-tile lists start at a fixed capacity and grow when a tile overflows: with capacities forced
+    far too small, mr_render (Scene.render) retries by itself and BandRenderer (frames enqueued without
+    host synchronisation) notices while priming; both end up with the frame of an unconstrained render."""
+    import torch
+    from py_numpy_renderer_amd.multigpu import BandRenderer
+    scene = scenes.build(api, "diablo_floor_small")
+    want = scene.render()
+    scene.close()
+
+    scene = scenes.build(api, "diablo_floor_small")
+    scene._backend().set_list_capacities(small_pairs=4, big_pairs=2, quads=3, work=16)
+    assert np.array_equal(scene.render(), want)
+    scene.close()
+
+    scene = scenes.build(api, "diablo_floor_small")
+    scene._backend().set_list_capacities(small_pairs=4, big_pairs=2, quads=3, work=16)
+    br = BandRenderer(scene, 0, 1, shadows=True, light_timing=True, frames_in_flight=2)
+    frames = [br.step() for _ in range(4)]
+    assert br.verify()
+    torch.cuda.synchronize()
+    for frame in frames[-2:]:
+        assert np.array_equal(frame.cpu().numpy(), want)
+    scene.close()
+
+
 def test_errors_are_loud(api):
     from py_numpy_renderer_amd import _native
     lib = _native.load_library()
@@ -129,12 +174,12 @@ def test_errors_are_loud(api):
     scene.close()
 
 
-FULL = ["c2_diablo_1080p", "c3_diablo_floor_1080p", "c4_torus200k_1080p", "c5_torus1m_4k_skybox"]
+FULL = ["c1_diablo_800x600", "c2_diablo_1080p", "c3_diablo_floor_1080p", "c4_torus200k_1080p", "c5_torus1m_4k_skybox"]
 
 
 @pytest.mark.parametrize("name", FULL)
 def test_full_size_config_matches_reference_capture(api, oracle_mod, name):
-    """BASELINE.json configs 2-5 (1920x1080; c5: 1M triangles + skybox at 3840x2160) against what the reference itself rendered
+    """BASELINE.json configs 1-5 (800x600, 1920x1080; c5: 1M triangles + skybox at 3840x2160) against what the reference itself rendered
     (uint8 frame, winner map, stencil and per-row sums of the z-buffer bit patterns are
     committed; the full float buffers are too large to commit, so they are checked against the
     oracle, which the CPU suite pins to the same captures)."""

@@ -1,8 +1,10 @@
-"""CPU suite: the N > 1 path (row-band split + ONE all-gather) with world_size 2 over gloo.
+"""CPU suite: the N > 1 path (screen-tile split + ONE all-gather) with world_size 2 and 3 over gloo.
 
-Each rank produces its band of the frame (here cut from the oracle's frame, since the HIP
-kernels need a GPU) and ``all_gather_frame`` must assemble exactly the golden frame on every
-rank.  The band arithmetic is the one bench.py and BandRenderer use on the GPUs."""
+Every rank renders ONLY the rows it owns -- with the oracle, since the HIP kernels need a GPU; the
+oracle takes the same ownership description the device gets (output-row band, or interleaved tile
+rows) -- lays them out the way the device lays out its output buffer, all-gathers, and (stripes)
+un-permutes.  What comes out on every rank must be the frame the reference rendered.  The band /
+stripe arithmetic and the un-permute are the ones bench.py and BandRenderer use on the GPUs."""
 import os
 import socket
 
@@ -14,7 +16,7 @@ import torch.multiprocessing as mp
 
 import scenes
 from conftest import load_golden
-from py_numpy_renderer_amd.multigpu import all_gather_frame, row_band
+from py_numpy_renderer_amd.multigpu import (all_gather_frame, row_band, stripe_rows, unstripe, unstripe_index)
 
 
 def test_row_band_partition():
@@ -27,33 +29,76 @@ def test_row_band_partition():
         row_band(10, 3, 2)
 
 
+def stripe_pack(frame, rank, world):
+    """A rank's output buffer in the striped layout (include/mi355rast.h, stripe_count), cut from a
+    frame whose rows the rank owns are valid: tile rows g = rank, rank + world, ... counted from the
+    bottom, highest first, rows inside a tile row top-down; unused rows stay zero."""
+    height = frame.shape[0]
+    per = stripe_rows(height, world)
+    part = np.zeros((per,) + frame.shape[1:], frame.dtype)
+    for py in range(height):
+        g = py // 16
+        if g % world != rank:
+            continue
+        local = g // world
+        part[(per // 16 - 1 - local) * 16 + (16 * g + 15 - py)] = frame[height - 1 - py]
+    return part
+
+
+@pytest.mark.parametrize("height,world", [(1080, 8), (1080, 3), (270, 2), (17, 4), (16, 3), (1, 2)])
+def test_unstripe_inverts_the_striped_layout(height, world):
+    frame = np.arange(height * 5 * 3, dtype=np.int64).reshape(height, 5, 3) % 251
+    frame = frame.astype(np.uint8)
+    gathered = np.concatenate([stripe_pack(frame, r, world) for r in range(world)], axis=0)
+    assert gathered.shape[0] == world * stripe_rows(height, world)
+    idx = unstripe_index(height, world)
+    assert sorted(set(idx.tolist())) == sorted(idx.tolist())          # every output row comes from its own source row
+    assert np.array_equal(unstripe(torch.from_numpy(gathered), height, world).numpy(), frame)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, frame_path, result_dir):
+def _worker(rank, world, port, name, partition, result_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        full = np.load(frame_path)
-        lo, hi = row_band(full.shape[0], rank, world)
-        part = torch.from_numpy(np.ascontiguousarray(full[lo:hi]))
-        frame = all_gather_frame(part)
+        from oracle import oracle
+        from py_numpy_renderer_amd._pack import pack_scene
+        scene = scenes.build(scenes.product_api(), name)
+        height = int(scene.resolution[0])
+        packed = pack_scene(scene, shadows=True)
+        if partition == "bands":
+            band = row_band(height, rank, world)
+            mine = oracle.render_packed(packed, own_rows=band, want_status=False, want_silhouette=False)
+            part = np.ascontiguousarray(mine.out[band[0]:band[1]])
+        else:
+            mine = oracle.render_packed(packed, own_stripe=(rank, world), want_status=False, want_silhouette=False)
+            part = stripe_pack(mine.out, rank, world)
+        # rows the rank does not own were not rendered: they still hold the background
+        other = np.ones(height, bool)
+        if partition == "bands":
+            other[band[0]:band[1]] = False
+        else:
+            other[[height - 1 - py for py in range(height) if (py // 16) % world == rank]] = False
+        assert (mine.winner[::-1][other] == -1).all(), "a rank rendered rows it does not own"
+        gathered = all_gather_frame(torch.from_numpy(part))
+        frame = gathered if partition == "bands" else unstripe(gathered, height, world)
         np.save(os.path.join(result_dir, f"rank{rank}.npy"), frame.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bands_all_gather_into_the_golden_frame(api, oracle_mod, tmp_path, world):
-    name = "diablo_floor_small"                      # 270 rows: splits evenly in 2 and 3
+@pytest.mark.parametrize("partition,world", [("bands", 2), ("bands", 3), ("stripes", 2), ("stripes", 3)])
+def test_ranks_render_their_tiles_and_gather_the_golden_frame(api, oracle_mod, tmp_path, partition, world):
+    name = "diablo_floor_small"                      # 270 rows: splits evenly in 2 and 3; 17 tile rows
     g, _ = load_golden(name)
-    frame = oracle_mod.render(scenes.build(api, name)).out
-    assert np.abs(frame.astype(int) - g["out"].astype(int)).max() <= 1
-    path = str(tmp_path / "frame.npy")
-    np.save(path, frame)
-    mp.spawn(_worker, args=(world, _free_port(), path, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, partition, str(tmp_path)), nprocs=world, join=True)
     for rank in range(world):
-        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), frame)
+        frame = np.load(tmp_path / f"rank{rank}.npy")
+        assert frame.shape == g["out"].shape
+        assert np.abs(frame.astype(int) - g["out"].astype(int)).max() <= 1, f"rank {rank}"
+    assert np.array_equal(np.load(tmp_path / "rank0.npy"), np.load(tmp_path / f"rank{world - 1}.npy"))

@@ -54,3 +54,25 @@ def test_invalid_arguments_are_rejected_without_a_gpu(lib):
     out = np.zeros(4, np.float64)
     assert lib.mr_read_z(handle, out.ctypes.data) < 0 and b"nothing rendered" in lib.mr_last_error()
     lib.mr_scene_destroy(handle)
+
+
+def test_integration_md_stub_matches_the_library(lib):
+    """The ctypes stub INTEGRATION.md tells a maintainer of the reference to paste (section B) must
+    describe the structs of THIS build: extracted from the document, executed against the built
+    library (its own assertions on mr_abi_struct_size run) and compared with the shipped binding."""
+    from py_numpy_renderer_amd import _native
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "class FrameDesc(C.Structure)" in b)
+    stub = stub.replace('C.CDLL("libmi355rast.so")', f'C.CDLL({_native.LIB_PATH!r})')
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md#B", "exec"), ns)
+    for ours, theirs in ((_native.FrameDesc, ns["FrameDesc"]), (_native.MaterialDesc, ns["Material"]),
+                         (_native.ModelDesc, ns["ModelDesc"])):
+        assert ctypes.sizeof(ours) == ctypes.sizeof(theirs)
+        assert [(n, ctypes.sizeof(t)) for n, t in ours._fields_] == [(n, ctypes.sizeof(t)) for n, t in theirs._fields_]
+    header = open(os.path.join(ROOT, "include", "mi355rast.h")).read()
+    body = re.search(r"typedef struct mr_frame_desc \{(.*?)\} mr_frame_desc;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    declared = re.findall(r"\b([a-z_0-9]+)(?:\[\d+\])?\s*[,;]", body)
+    assert declared == [n for n, _ in ns["FrameDesc"]._fields_]

@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box): timeline of the visibility kernel's workgroups."""
+"""Diagnostic (GPU box): timeline of the tile kernel's workgroups."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -10,12 +10,12 @@ shadows = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
 sc = scenes.build(api, name)
 be = sc._backend()
 for _ in range(5):
-    be.render(sc, shadows=shadows)
+    be.render(sc, shadows=shadows, counters=False)
 r = be.read_tile_records().astype(np.int64)
-start, end = r[:, 5], r[:, 6]
+start, end = r[:, 8], r[:, 9]
 t0 = start.min()
 dur = (end - start) * 10e-3          # us
-small, big, quads = r[:, 7] & 0xfff, (r[:, 7] >> 12) & 0x3ff, (r[:, 7] >> 22) & 0x3ff
+small, big, quads = r[:, 5], r[:, 6], r[:, 7]
 print("tiles", len(r), "kernel span us", (end.max() - t0) * 10e-3, "sum dur us", dur.sum(), "mean", dur.mean(), "max", dur.max())
 print("list sizes: small max", small.max(), "sum", small.sum(), "| big max", big.max(), "sum", big.sum(), "| quads max", quads.max(), "sum", quads.sum())
 order = np.argsort(-dur)[:8]
@@ -23,6 +23,17 @@ for i in order:
     print(f"  tile {i}: dur {dur[i]:.1f} us start +{(start[i]-t0)*10e-3:.1f} small {small[i]} big {big[i]} quads {quads[i]}")
 for lo, hi in ((0, 1), (1, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 1000)):
     m = (dur >= lo) & (dur < hi)
-    print(f"  dur [{lo},{hi}) us: {m.sum()} tiles, mean small {small[m].mean() if m.any() else 0:.1f} quads {quads[m].mean() if m.any() else 0:.1f}")
+    print(f"  dur [{lo},{hi}) us: {m.sum()} tiles, sum {dur[m].sum():.0f} us, mean small {small[m].mean() if m.any() else 0:.1f} big {big[m].mean() if m.any() else 0:.1f} quads {quads[m].mean() if m.any() else 0:.1f}")
 st = (start - t0) * 10e-3
 print("start-time percentiles us:", np.percentile(st, [10, 50, 90, 99, 100]).round(1))
+en = (end - t0) * 10e-3
+print("end-time percentiles us:", np.percentile(en, [10, 50, 90, 99, 100]).round(1))
+# classes of tiles
+empty = (small == 0) & (big == 0) & (quads == 0)
+print("empty tiles", empty.sum(), "mean dur", dur[empty].mean() if empty.any() else 0)
+only_big = (small == 0) & (big > 0) & (quads == 0)
+print("big-only tiles", only_big.sum(), "mean dur", dur[only_big].mean() if only_big.any() else 0)
+mesh = small > 0
+print("mesh tiles", mesh.sum(), "mean dur", dur[mesh].mean() if mesh.any() else 0)
+q = quads > 0
+print("quad tiles", q.sum(), "mean dur", dur[q].mean() if q.any() else 0)
