@@ -225,7 +225,8 @@ int mr_read_silhouette(mr_scene *scene, int32_t *out_triples, int32_t cap);
 /* Diagnostics: the tile kernel's per-tile records of the last frame, MR_TILE_RECORD_WORDS uint32 per tile:
  * [0..4] triangle fragments, quad fragments, stencil updates, covered px, lit px (MR_FRAME_COUNTERS);
  * [5..7] lengths of the tile's lists: small triangle pairs, big triangle pairs, shadow quads;
- * [8],[9] start and end of the tile's workgroup in 10 ns ticks (low 32 bits); [10],[11] reserved.
+ * [8],[9] start and end of the tile's workgroup in 10 ns ticks (low 32 bits); [10],[11] the ticks at
+ * which its coverage / z phase and its shadow-quad phase ended.
  * Returns the number of tiles (tiles are 16 x 16 px, row-major over the rendered rows) or a negative error. */
 #define MR_TILE_RECORD_WORDS 12
 int mr_debug_read_tile_records(mr_scene *scene, uint32_t *out, int32_t cap_tiles);

@@ -75,7 +75,7 @@ struct BinArgs {
 
 constexpr int TILE_STATS = 5;     // per-tile partial counters written by the tile kernel
 constexpr int TILE_REC = 12;      // words per tile record: counters, list lengths, start / end time (10 ns ticks)
-constexpr int QUAD_BATCH = 16;    // shadow quads staged in LDS per round of the tile kernel
+constexpr int QUAD_BATCH = 64;    // shadow quads staged in LDS per round of the tile kernel: one per lane of a wavefront
 constexpr int BIN_SMALL = 4;      // triangles touching <= this many tiles are binned by their own lane
 constexpr uint32_t WORK_QUAD = 0x80000000u;
 

@@ -83,21 +83,29 @@ k_edge_normals(int n_edges, EdgeRec *__restrict__ edges, const double *__restric
 // 1 / clip.w, ndc = clip * depth, screen = ndc @ viewport; plus linearize_z of the screen z.
 struct CornerOut {
     double sx, sy, sz, depth, zlin;
-    double clip[4], clipd[4];
     bool safe;
 };
 
-__device__ __forceinline__ void xform_vertex(const FrameConst &fc, const double v[4], CornerOut &o)
+// v @ camera.MVP and v @ debug_camera.MVP of one corner
+__device__ __forceinline__ void clip_coords(const FrameConst &fc, const double v[4], double clip[4], double clipd[4])
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        o.clip[j] = row_times_col(v, fc.mvp, j);
-        o.clipd[j] = fc.same_clip ? o.clip[j] : row_times_col(v, fc.debug_mvp, j);
+        clip[j] = row_times_col(v, fc.mvp, j);
+        clipd[j] = fc.same_clip ? clip[j] : row_times_col(v, fc.debug_mvp, j);
     }
-    o.depth = 1.0 / o.clip[3];
+}
+
+__device__ __forceinline__ void xform_vertex(const FrameConst &fc, const double v[4], CornerOut &o)
+{
+    // the clip-space coordinates are not kept: the few faces that need them for the per-fragment
+    // clip test recompute them (clip_coords), which is cheaper than 48 live registers in every lane
+    double clip[4], clipd[4];
+    clip_coords(fc, v, clip, clipd);
+    o.depth = 1.0 / clip[3];
     double ndc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ndc[j] = o.clip[j] * o.depth;
+    for (int j = 0; j < 4; ++j) ndc[j] = clip[j] * o.depth;
     o.sx = row_times_col(ndc, fc.viewport, 0);
     o.sy = row_times_col(ndc, fc.viewport, 1);
     o.sz = row_times_col(ndc, fc.viewport, 2);
@@ -108,9 +116,9 @@ __device__ __forceinline__ void xform_vertex(const FrameConst &fc, const double 
     // when all three corners carry this flag the strict test of obj/triangular.py:85-87 cannot
     // fail for any fragment of the face and need not be evaluated.
     const double k = 1.0 - 1e-12;
-    const double wl = o.clip[3] * k, wd = o.clipd[3] * k;
-    o.safe = fabs(o.clip[0]) < wl && fabs(o.clip[1]) < wl && fabs(o.clip[2]) < wl &&
-             fabs(o.clipd[0]) < wd && fabs(o.clipd[1]) < wd && fabs(o.clipd[2]) < wd;
+    const double wl = clip[3] * k, wd = clipd[3] * k;
+    o.safe = fabs(clip[0]) < wl && fabs(clip[1]) < wl && fabs(clip[2]) < wl &&
+             fabs(clipd[0]) < wd && fabs(clipd[1]) < wd && fabs(clipd[2]) < wd;
 }
 
 // The vertex stage on the matrix cores, once per unique vertex.  The two products of
@@ -360,11 +368,9 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
                 cl.clipd[0][j] = ca.clipd[j]; cl.clipd[1][j] = cb.clipd[j]; cl.clipd[2][j] = cc.clipd[j];
             }
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                cl.clip[0][j] = A.clip[j]; cl.clip[1][j] = B.clip[j]; cl.clip[2][j] = C.clip[j];
-                cl.clipd[0][j] = A.clipd[j]; cl.clipd[1][j] = B.clipd[j]; cl.clipd[2][j] = C.clipd[j];
-            }
+            clip_coords(fc, va, cl.clip[0], cl.clipd[0]);
+            clip_coords(fc, vb, cl.clip[1], cl.clipd[1]);
+            clip_coords(fc, vc, cl.clip[2], cl.clipd[2]);
         }
     }
     return count_here ? 1 : 3;
@@ -737,7 +743,7 @@ __device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs
 
 // First launch of the frame: workgroups [0, face_blocks) set faces up, the rest look at edges.
 template <bool PRE_XFORM>
-__global__ void __launch_bounds__(SETUP_BLOCK)
+__global__ void __launch_bounds__(SETUP_BLOCK, 4)
 k_setup(const FrameConst fc, const SetupArgs sa, const BinArgs bins, uint32_t face_blocks)
 {
     if (blockIdx.x < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, blockIdx.x);

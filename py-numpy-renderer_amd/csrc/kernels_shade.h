@@ -62,56 +62,6 @@ __device__ __forceinline__ void c_normalize3(const double a[3], double o[3])
     o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
 }
 
-// 3x3 inverse by LU with partial pivoting (np.linalg.inv -> LAPACK gesv).  Rows are swapped
-// by value, never indexed dynamically, so everything stays in registers.
-__device__ __forceinline__ void swap_rows(bool c, double x[3], double y[3], int &px, int &py)
-{
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { const double t = x[j]; x[j] = c ? y[j] : x[j]; y[j] = c ? t : y[j]; }
-    const int t = px; px = c ? py : px; py = c ? t : py;
-}
-__device__ __forceinline__ bool inv3(const double a[3][3], double inv[3][3])
-{
-    double r0[3] = { a[0][0], a[0][1], a[0][2] }, r1[3] = { a[1][0], a[1][1], a[1][2] },
-           r2[3] = { a[2][0], a[2][1], a[2][2] };
-    int p0 = 0, p1 = 1, p2 = 2;
-    // column 0: first row of maximal |.| (idamax)
-    {
-        const bool one = fabs(r1[0]) > fabs(r0[0]);
-        const double best = one ? fabs(r1[0]) : fabs(r0[0]);
-        const bool two = fabs(r2[0]) > best;
-        if ((two ? fabs(r2[0]) : best) == 0) return false;
-        swap_rows(one && !two, r0, r1, p0, p1);
-        swap_rows(two, r0, r2, p0, p2);
-        const double r = c_rcp(r0[0]);
-        r1[0] *= r; r2[0] *= r;
-        r1[1] = fma(-r1[0], r0[1], r1[1]); r1[2] = fma(-r1[0], r0[2], r1[2]);
-        r2[1] = fma(-r2[0], r0[1], r2[1]); r2[2] = fma(-r2[0], r0[2], r2[2]);
-    }
-    {
-        const bool two = fabs(r2[1]) > fabs(r1[1]);
-        if ((two ? fabs(r2[1]) : fabs(r1[1])) == 0) return false;
-        swap_rows(two, r1, r2, p1, p2);
-        const double r = c_rcp(r1[1]);
-        r2[1] *= r;
-        r2[2] = fma(-r2[1], r1[2], r2[2]);
-    }
-    if (fabs(r2[2]) == 0) return false;
-    const double rd0 = c_rcp(r0[0]), rd1 = c_rcp(r1[1]), rd2 = c_rcp(r2[2]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        // L y = P e_j, then U x = y
-        const double y0 = p0 == j ? 1.0 : 0.0;
-        const double y1 = fma(-r1[0], y0, p1 == j ? 1.0 : 0.0);
-        const double y2 = fma(-r2[1], y1, fma(-r2[0], y0, p2 == j ? 1.0 : 0.0));
-        const double x2 = y2 * rd2;
-        const double x1 = fma(-r1[2], x2, y1) * rd1;
-        const double x0 = fma(-r0[2], x2, fma(-r0[1], x1, y0)) * rd0;
-        inv[0][j] = x0; inv[1][j] = x1; inv[2][j] = x2;
-    }
-    return true;
-}
-
 // ndarray ** scalar: NumPy's scalar-exponent fast paths; small whole exponents (the default
 // Ns = 64) by repeated squaring; else pow()
 __device__ __forceinline__ double np_power(double x, double e)
@@ -245,28 +195,35 @@ __device__ __forceinline__ void shade_pixel(const FrameConst &fc, const TriRec &
     if (mat.map_norm.rgb) {
         const float *tx = texel(mat.map_norm, tu, tv);
         if (mat.norm_tangent) {
-            double n[3], A[3][3], AI[3][3];
+            // tangent_ (obj/core.py:191-224): T = normalize(AI @ (du, 0)), B = normalize(AI @ (dv, 0)) with
+            // AI = inv([b - a; c - a; n]).  The third component of (du, 0) and (dv, 0) is zero, so only
+            // the first two columns of the inverse are used: (e2 x n) / det and (n x e1) / det, and the
+            // normalisation cancels |det|: no LU, no division, just two cross products and the sign of
+            // the determinant.  Agrees with the LAPACK inverse to cond(A) * 1e-16, seven orders inside
+            // the float32 the colour is stored in.  A singular A gives NaN (upstream's inv raises).
+            double n[3], e1[3], e2[3];
             c_normalize3(interp, n);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 if (ff & FF_VERTS_F32) {
-                    A[0][j] = (double)((float)wb[j] - (float)wa[j]);
-                    A[1][j] = (double)((float)wc[j] - (float)wa[j]);
+                    e1[j] = (double)((float)wb[j] - (float)wa[j]);
+                    e2[j] = (double)((float)wc[j] - (float)wa[j]);
                 } else {
-                    A[0][j] = wb[j] - wa[j];
-                    A[1][j] = wc[j] - wa[j];
+                    e1[j] = wb[j] - wa[j];
+                    e2[j] = wc[j] - wa[j];
                 }
-                A[2][j] = n[j];
             }
-            if (!inv3(A, AI))
-                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) AI[i][j] = NAN;
-            const double du[2] = { (double)(at.uv[1][0] - at.uv[0][0]), (double)(at.uv[2][0] - at.uv[0][0]) };
-            const double dv[2] = { (double)(at.uv[1][1] - at.uv[0][1]), (double)(at.uv[2][1] - at.uv[0][1]) };
+            const double c0[3] = { e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0] };
+            const double c1[3] = { n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0] };
+            const double det = (e1[0] * c0[0] + e1[1] * c0[1]) + e1[2] * c0[2];
+            const double sgn = det > 0 ? 1.0 : (det < 0 ? -1.0 : NAN);
+            const double du[2] = { (double)(at.uv[1][0] - at.uv[0][0]) * sgn, (double)(at.uv[2][0] - at.uv[0][0]) * sgn };
+            const double dv[2] = { (double)(at.uv[1][1] - at.uv[0][1]) * sgn, (double)(at.uv[2][1] - at.uv[0][1]) * sgn };
             double ti_[3], tj_[3], T[3], Bt[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                ti_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], du[0], du[1], 0.0);
-                tj_[r] = chain3(AI[r][0], AI[r][1], AI[r][2], dv[0], dv[1], 0.0);
+                ti_[r] = fma(c1[r], du[1], c0[r] * du[0]);
+                tj_[r] = fma(c1[r], dv[1], c0[r] * dv[0]);
             }
             c_normalize3(ti_, T);
             c_normalize3(tj_, Bt);

@@ -10,7 +10,7 @@
 //
 // Phases of a tile (k_tile):
 //   1. big (triangle, tile) pairs -- a floor triangle -- one PIXEL per thread, the records staged
-//      64 at a time in registers and broadcast with v_readlane (obj/triangular.py:72-118);
+//      64 at a time in LDS and read as broadcasts (obj/triangular.py:72-118);
 //   2. small pairs -- a dense mesh's triangles cover a handful of samples -- four lanes per
 //      TRIANGLE: they share out the few samples of the pixel box and do an LDS atomicMin on the
 //      order-preserving key of z, then (second sweep) an LDS atomicMax of the face index where its
@@ -28,21 +28,6 @@
 #include "kernels_shade.h"
 
 namespace mr {
-
-// ---- register staging: every lane fetches one primitive record of the tile's list, then the
-// records are broadcast one at a time with v_readlane (uniform values land in SGPRs, with no
-// memory latency in the inner loop and no LDS traffic).
-__device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-__device__ __forceinline__ float bcast(float v, int src)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-__device__ __forceinline__ double bcast(double v, int src)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 
 // Order-preserving key of a non-NaN double: unsigned comparison of keys == comparison of values.
 __device__ __forceinline__ unsigned long long z_key(double z)
@@ -111,7 +96,7 @@ __device__ __forceinline__ int out_row(const FrameConst &fc, int py, int l)
 
 constexpr int QUAD_STAGE_U4 = 12;     // uint4 pieces staged per quad: 64-byte header + 4 edges
 static_assert(offsetof(QuadRec, e) == 64 && sizeof(QuadEdge) == 32, "QuadRec layout");
-static_assert(QUAD_BATCH * QUAD_STAGE_U4 <= TILE_PX, "one lane stages one 16-byte piece of the batch's records");
+static_assert(QUAD_BATCH == WAVE, "lane j of every wavefront classifies quad j of the batch");
 
 struct QuadHead {                     // the first 64 bytes of a QuadRec, as staged
     double nx, ny, nz, d;
@@ -199,12 +184,6 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         tile = (int)blockIdx.x - HEAVY_FRONT;
         if (ta.heavy_flag[tile]) return;
     }
-    s_gamma[tid] = sh.gamma_lut[tid];
-    if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
-    const bool mat_lds = fc.n_materials <= MAT_LDS;
-    if (mat_lds && tid < fc.n_materials * (int)(sizeof(Material) / 8))
-        s_mat[tid] = reinterpret_cast<const unsigned long long *>(sh.materials)[tid];
-
     const int ltr = tile / fc.tiles_x;                    // local tile row
     const int gx = (tile % fc.tiles_x) * TILE_W, gy = tile_row_frame(fc, ltr) * TILE_H;
     const int lp = tid;                                   // pixel of this thread inside the tile
@@ -217,32 +196,66 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     const uint32_t n_small_raw = ta.bin_count[tile], n_big_raw = ta.bin_count[n_tiles + tile],
                    n_quad_raw = ta.bin_count[2 * n_tiles + tile];
     const uint32_t n_small = min(n_small_raw, ta.cap[0]), n_big = min(n_big_raw, ta.cap[1]), n_quad = min(n_quad_raw, ta.cap[2]);
+    // the heaviest tiles are the frame's critical path: their wavefronts go first wherever they
+    // compete with a lighter tile's for a SIMD's issue slots
+    const uint32_t cost = tile_cost(n_small_raw, n_big_raw, n_quad_raw);
+    if (cost >= 900u) __builtin_amdgcn_s_setprio(3);
+    else if (cost >= 400u) __builtin_amdgcn_s_setprio(1);
     const uint32_t *__restrict__ small_items = ta.items[0] + (size_t)tile * ta.cap[0];
     const uint32_t *__restrict__ big_items = ta.items[1] + (size_t)tile * ta.cap[1];
     const uint32_t *__restrict__ quad_items = ta.items[2] + (size_t)tile * ta.cap[2];
+
+    // Nothing listed for this tile (a third of a typical frame): its pixels show the background, which
+    // the host has finalised already.  Shadow quads over it only matter to the counters.
+    if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (fc.background_u8 >> 24) &&
+        !((fc.flags & MR_FRAME_SKYBOX) && sh.sky) && !sh.frame && !ta.zbuf) {
+        if (live) {
+            uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
+            o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
+        }
+        if (tid == 0) {
+            uint32_t *rec = ta.tile_stats + (size_t)tile * TILE_REC;
+            for (int k = 0; k < TILE_REC; ++k) rec[k] = 0;
+            rec[7] = n_quad_raw;
+            rec[8] = rec[10] = rec[11] = (uint32_t)t_start;
+            rec[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            ta.bin_count[2 * n_tiles + tile] = 0;
+            ta.next_heavy_flag[tile] = 0;
+        }
+        return;
+    }
     if (tid < TILE_STATS) s_cnt[tid] = 0;
+    s_gamma[tid] = sh.gamma_lut[tid];
+    if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
+    const bool mat_lds = fc.n_materials <= MAT_LDS;
+    if (mat_lds && tid < fc.n_materials * (int)(sizeof(Material) / 8))
+        s_mat[tid] = reinterpret_cast<const unsigned long long *>(sh.materials)[tid];
 
     // ---- 1. big pairs, one pixel per thread (obj/triangular.py:72-118)
     double zbest = rh ? INFINITY : -INFINITY;
     int best = -1;
     unsigned int frags = 0;
+    // The records of up to 64 pairs are copied to LDS once per workgroup, 16 bytes per lane and step
+    // (the staging area of the shadow quads, not in use yet), and every lane then reads the pair it is
+    // testing at the same LDS address (a broadcast read).  Each wavefront fetching the records itself,
+    // one per lane, and handing them round with v_readlane cost ~45 vector instructions per pair and
+    // wavefront on top of the arithmetic; scalar loads cost a dependent memory round trip per pair.
+    constexpr int TRI_U4 = (int)(sizeof(TriRec) / 16);
+    static_assert(WAVE * TRI_U4 <= QUAD_BATCH * QUAD_STAGE_U4, "big-pair records are staged in the quad area");
     for (uint32_t base = 0; base < n_big; base += WAVE) {
         const int n = (int)min((uint32_t)WAVE, n_big - base);
-        const TriRec mine = tris[lane < n ? big_items[base + lane] : big_items[base]];
-        const int m_bx = (int)(uint16_t)mine.x0 | ((int)(uint16_t)mine.x1 << 16);
-        const int m_by = (int)(uint16_t)mine.y0 | ((int)(uint16_t)mine.y1 << 16);
+        if (base) __syncthreads();                        // the previous chunk has been read
+        for (int i = tid; i < n * TRI_U4; i += TILE_PX) {
+            const int q = i / TRI_U4, piece = i - q * TRI_U4;
+            s_quad[i] = reinterpret_cast<const uint4 *>(tris + big_items[base + q])[piece];
+        }
+        __syncthreads();
         for (int j = 0; j < n; ++j) {
-            TriRec t;
-            t.ax = bcast(mine.ax, j); t.ay = bcast(mine.ay, j);
-            t.v0x = bcast(mine.v0x, j); t.v0y = bcast(mine.v0y, j);
-            t.v1x = bcast(mine.v1x, j); t.v1y = bcast(mine.v1y, j);
-            t.d00 = bcast(mine.d00, j); t.d01 = bcast(mine.d01, j);
-            t.d11 = bcast(mine.d11, j); t.inv_den = bcast(mine.inv_den, j);
-            const int bx = bcast(m_bx, j), by = bcast(m_by, j);
-            const uint32_t flags = (uint32_t)bcast((int)mine.flags, j);
-            const int f = bcast(mine.face, j);
+            const TriRec &t = *reinterpret_cast<const TriRec *>(s_quad + j * TRI_U4);
+            const uint32_t flags = t.flags;
+            const int f = t.face;
             const bool single = (flags & TF_SINGLE_BOX) != 0;
-            bool in = live && px >= (bx & 0xffff) && px < (bx >> 16) && py >= (by & 0xffff) && py < (by >> 16);
+            bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
             float u, v, w;
             tri_bary(t, dpx, dpy, single, u, v, w);
             in = in && u >= 0 && v >= 0 && w >= 0;
@@ -258,8 +271,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                     in = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
                 }
             }
-            const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
-                                       bcast(mine.zl0, j), bcast(mine.zl1, j), bcast(mine.zl2, j));
+            const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
             // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
             const bool closer = rh ? (z < zbest) : (z > zbest);
             if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
@@ -267,30 +279,33 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     }
     __syncthreads();                                      // s_cnt is zeroed, the LDS tables are loaded
     if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
-    s_key[lp] = z_key(zbest);
-    __syncthreads();
+    if (n_small) {
+        s_key[lp] = z_key(zbest);
+        __syncthreads();
 
-    // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
-    unsigned int sfrags = 0;
-    for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
-        const TriRec t = tris[small_items[i]];
-        small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
-    }
-    if (sfrags) atomicAdd(&s_cnt[0], sfrags);
-    __syncthreads();
+        // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
+        unsigned int sfrags = 0;
+        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
+            const TriRec t = tris[small_items[i]];
+            small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+        }
+        if (sfrags) atomicAdd(&s_cnt[0], sfrags);
+        __syncthreads();
 
-    // winners: big pairs keep their face where their z survived, then the small pairs' sweep
-    const unsigned long long kfinal = s_key[lp];
-    s_win[lp] = (best >= 0 && kfinal == z_key(zbest)) ? best : -1;
-    __syncthreads();
-    for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
-        const TriRec t = tris[small_items[i]];
-        small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+        // winners: big pairs keep their face where their z survived, then the small pairs' sweep
+        const unsigned long long kfinal = s_key[lp];
+        s_win[lp] = (best >= 0 && kfinal == z_key(zbest)) ? best : -1;
+        __syncthreads();
+        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
+            const TriRec t = tris[small_items[i]];
+            small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+        }
+        __syncthreads();
+        best = s_win[lp];
+        zbest = z_unkey(kfinal);
     }
-    __syncthreads();
-    best = s_win[lp];
-    zbest = z_unkey(kfinal);
     const bool covered = live && best >= 0;
+    const unsigned long long t_raster = __builtin_amdgcn_s_memrealtime();
 
     // ---- 3. shadow quads against the final z: stencil +-1 (obj/triangular.py:335-368).  The
     // batch's records (header and first four edges: 192 bytes each) are copied to LDS once, 16 bytes
@@ -299,24 +314,37 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     // (obj/triangular.py:365-368); the count stays in this thread's register.
     int sten = 0;
     unsigned int qfrags = 0, qupd = 0;
-    if (n_quad) {
-        // most favourable covered z of this wavefront's strip (see the depth cull below)
-        double zlim = rh ? -INFINITY : INFINITY;
-        if (!counters) {
-            if (covered) zlim = zbest;
+    // without the counters only the frame is the contract: the stencil matters where a triangle was drawn
+    if (n_quad && (counters || __syncthreads_or(covered))) {
+        // most and least favourable covered z of this wavefront's strip (see the depth verdicts below)
+        double zlim = rh ? -INFINITY : INFINITY, zhard = rh ? INFINITY : -INFINITY;
+        if (covered) zlim = zhard = zbest;
 #pragma unroll
-            for (int off = WAVE / 2; off; off >>= 1) {
-                const double o = __shfl_xor(zlim, off);
-                zlim = rh ? fmax(zlim, o) : fmin(zlim, o);
-            }
+        for (int off = WAVE / 2; off; off >>= 1) {
+            const double o = __shfl_xor(zlim, off), h = __shfl_xor(zhard, off);
+            zlim = rh ? fmax(zlim, o) : fmin(zlim, o);
+            zhard = rh ? fmin(zhard, h) : fmax(zhard, h);
         }
         for (uint32_t qbase = 0; qbase < n_quad; qbase += QUAD_BATCH) {
             const int n = (int)min((uint32_t)QUAD_BATCH, n_quad - qbase);
             if (qbase) __syncthreads();                   // the previous batch has been read
-            if (tid < n * QUAD_STAGE_U4) {
-                const int q = tid / QUAD_STAGE_U4, piece = tid - q * QUAD_STAGE_U4;
+            // Staging also folds two per-quad facts into the copy: a back-facing quad's edge vectors are
+            // negated (the rounded cross product changes sign exactly, so "inner side" is "> 0" for every
+            // staged quad), and the last 16 bytes of the header, unused here, receive f_plus_n * nz and
+            // two_nf * nz of the depth test below.
+            for (int i = tid; i < n * QUAD_STAGE_U4; i += TILE_PX) {
+                const int q = i / QUAD_STAGE_U4, piece = i - q * QUAD_STAGE_U4;
                 const uint32_t id = quad_items[qbase + q];
-                s_quad[tid] = reinterpret_cast<const uint4 *>(ta.quads + id)[piece];
+                const QuadRec *src = ta.quads + id;
+                uint4 val = reinterpret_cast<const uint4 *>(src)[piece];
+                if (piece == 3) {
+                    const double a0 = fc.f_plus_n * src->nz, b0 = fc.two_nf * src->nz;
+                    val = make_uint4((uint32_t)__double2loint(a0), (uint32_t)__double2hiint(a0),
+                                     (uint32_t)__double2loint(b0), (uint32_t)__double2hiint(b0));
+                } else if (piece >= 5 && (piece & 1) && !src->is_front) {
+                    val.y ^= 0x80000000u; val.w ^= 0x80000000u;
+                }
+                s_quad[i] = val;
                 if (piece == 0) s_id[q] = id;
             }
             __syncthreads();
@@ -327,95 +355,107 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
             // side of some edge -> no sample of the strip is inside (skip the quad); all four
             // corners on the inner side of every edge -> every sample is inside (skip the
             // per-pixel edge tests).  Exact, no margins.
-            bool q_reject = lane >= n, q_accept = false;
+            // Per edge too: an edge whose inner side holds all four corners needs no per-pixel test
+            // in this strip (bit i of emask clear); typically one edge of a quad crosses a strip.
+            bool q_reject = lane >= n;
+            int emask = 0;
             if (!q_reject) {
                 const QuadHead &h = *reinterpret_cast<const QuadHead *>(s_quad + lane * QUAD_STAGE_U4);
                 const QuadEdge *e = reinterpret_cast<const QuadEdge *>(s_quad + lane * QUAD_STAGE_U4 + 4);
                 const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
                 const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
-                const bool front = h.is_front != 0;
-                q_accept = h.n <= 4;
+                if (h.n > 4) emask |= 16;                   // edges beyond the staged four: always per pixel
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i < 3 || h.n > 3) {
                         const double px0 = (xa - e[i].sx) * e[i].ey, px1 = (xb - e[i].sx) * e[i].ey;
                         const double py0 = (ya - e[i].sy) * e[i].ex, py1 = (yb - e[i].sy) * e[i].ex;
                         const double c00 = px0 - py0, c10 = px1 - py0, c01 = px0 - py1, c11 = px1 - py1;
-                        const bool any = front ? (c00 > 0 || c10 > 0 || c01 > 0 || c11 > 0)
-                                               : (c00 < 0 || c10 < 0 || c01 < 0 || c11 < 0);
-                        const bool all = front ? (c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0)
-                                               : (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0);
+                        const bool any = c00 > 0 || c10 > 0 || c01 > 0 || c11 > 0;
+                        const bool all = c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0;
                         q_reject = q_reject || !any;
-                        q_accept = q_accept && all;
+                        if (!all) emask |= 1 << i;
                     }
                 }
             }
-            if (!counters && !q_reject) {
-                // Depth cull, only when the frame is all that is asked for (no MR_FRAME_COUNTERS):
-                // the stencil matters where a triangle was drawn, and a quad changes it only where
-                // its depth passes against the z-buffer.  The quad's plane depth is affine over the
-                // screen, so over the strip -t/nz is extreme at a corner, and linearize_z is
-                // monotone while its denominator stays positive: if even the most favourable depth
-                // of the quad over the strip (pushed further by a slack that dwarfs the rounding of
-                // the per-pixel expression) loses against the most favourable covered z of the
-                // strip, no pixel of the strip can pass.  Nine in ten quad fragments fail the
-                // depth test in a typical frame.
+            // Depth verdicts for the whole strip.  The quad's plane depth is affine over the screen, so
+            // over the strip -t/nz is extreme at a corner, and linearize_z is monotone while its
+            // denominator stays positive: with 0 < den_lo <= den <= den_hi over the strip (bounds pushed
+            // outwards by a slack that dwarfs the rounding of the per-pixel expression and of the
+            // approximate reciprocal used here) the depth two_nf / den lies in [two_nf / den_hi,
+            // two_nf / den_lo], and comparisons against it are decided without dividing.
+            //   all pass: even the quad's least favourable depth passes against the least favourable
+            //             covered z of the strip (uncovered pixels pass anyway: their z is +-inf) ->
+            //             the per-pixel depth arithmetic is skipped, the verdict is the same;
+            //   none can: (only when the frame is all that is asked for, no MR_FRAME_COUNTERS: the
+            //             stencil matters where a triangle was drawn) even its most favourable depth
+            //             loses against the most favourable covered z -> the quad is skipped.
+            bool q_allpass = false;
+            if (!q_reject) {
                 const QuadHead &h = *reinterpret_cast<const QuadHead *>(s_quad + lane * QUAD_STAGE_U4);
                 const double xa = (double)gx, xb = (double)(gx + TILE_W - 1);
                 const double ya = (double)(gy + (tid / WAVE) * (WAVE / TILE_W)), yb = ya + (double)(WAVE / TILE_W - 1);
                 const double t00 = (h.nx * xa + h.ny * ya) + h.d, t10 = (h.nx * xb + h.ny * ya) + h.d;
                 const double t01 = (h.nx * xa + h.ny * yb) + h.d, t11 = (h.nx * xb + h.ny * yb) + h.d;
                 const double tmin = fmin(fmin(t00, t10), fmin(t01, t11)), tmax = fmax(fmax(t00, t10), fmax(t01, t11));
-                const double inz = 1.0 / h.nz;
+                const double inz = approx_rcp(h.nz);
                 const double za = -tmin * inz, zb = -tmax * inz;
                 const double slack = 1e-12 * fmax(fabs(za), fabs(zb)) +
                                      1e-15 * ((fabs(h.nx) * xb + fabs(h.ny) * yb) + fabs(h.d)) * fabs(inz);
                 const double zs_lo = fmin(za, zb) - slack, zs_hi = fmax(za, zb) + slack;
                 const double den_lo = fc.f_plus_n - zs_hi * fc.f_minus_n, den_hi = fc.f_plus_n - zs_lo * fc.f_minus_n;
-                // den_lo <= den <= den_hi over the strip; for 0 < den the depth two_nf / den falls as den grows
-                const bool sane = fc.two_nf > 0 && fc.f_minus_n > 0 && den_lo > 1e-9 * fc.f_plus_n;
-                const double zq_lo = fc.two_nf / den_hi * (1.0 - 1e-12), zq_hi = fc.two_nf / den_lo * (1.0 + 1e-12);
-                if (sane && (rh ? zq_lo > zlim : zq_hi < zlim)) q_reject = true;
+                const bool sane = fc.two_nf > 0 && fc.f_minus_n > 0 && den_lo > 1e-9 * fc.f_plus_n && h.nz != 0 &&
+                                  fabs(inz) < 1e300 && den_hi < 1e300;
+                const double lo = fc.two_nf * (1.0 - 1e-12), hi = fc.two_nf * (1.0 + 1e-12);
+                // rh: a pixel passes when zbuf >= zq; lh: when zbuf <= zq
+                const bool none = rh ? lo > zlim * den_hi : hi < zlim * den_lo;
+                const bool all = rh ? hi <= zhard * den_lo : lo >= zhard * den_hi;
+                if (sane && !counters && none) q_reject = true;
+                q_allpass = sane && all;
             }
             unsigned long long todo = __ballot(!q_reject);
-            const unsigned long long accepted = __ballot(q_accept);
+            const unsigned long long allpass = __ballot(q_allpass);
 
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                // the whole record is fetched up front with plain 16-byte broadcast reads and the
-                // tests below are combined without short-circuits: written with && the compiler
-                // kept one LDS load per condition, each behind its own branch and wait
+                // The whole record is fetched up front with 16-byte broadcast reads (every lane the same
+                // LDS address) behind ONE wait: a heavy tile walks 50-100 quads one after the other, and
+                // a read issued only where its value is needed puts an LDS round trip on that serial
+                // chain each time (measured: 0.5 us per quad against 0.2).  Which edges need the per-pixel
+                // test is wavefront-uniform (lane j's verdict), so the skipped ones cost no arithmetic.
                 const uint4 *rec = s_quad + j * QUAD_STAGE_U4;
-                const uint4 hb = rec[2];
+                const uint4 p0 = rec[0], p1 = rec[1], hb = rec[2], p3 = rec[3];
                 const uint4 ea0 = rec[4], eb0 = rec[5], ea1 = rec[6], eb1 = rec[7], ea2 = rec[8], eb2 = rec[9],
                             ea3 = rec[10], eb3 = rec[11];
+                const int em = __builtin_amdgcn_readlane(emask, j);
                 const int x0 = (int)(int16_t)(hb.x & 0xffffu), x1 = (int)(int16_t)(hb.x >> 16);
                 const int y0 = (int)(int16_t)(hb.y & 0xffffu), y1 = (int)(int16_t)(hb.y >> 16);
                 const int nv = (int)hb.z;
                 const bool front = hb.w != 0;
                 bool in = live & (px >= x0) & (px < x1) & (py >= y0) & (py < y1);
-                if (!((accepted >> j) & 1)) {
-                    auto d2 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
-                    auto inner = [&](const uint4 &a, const uint4 &b) {
-                        const double ax = dpx - d2(a.x, a.y), ay = dpy - d2(a.z, a.w);
-                        const double cr = ax * d2(b.z, b.w) - ay * d2(b.x, b.y);
-                        return front ? cr > 0 : cr < 0;
-                    };
-                    const bool i0 = inner(ea0, eb0), i1 = inner(ea1, eb1), i2 = inner(ea2, eb2), i3 = inner(ea3, eb3);
-                    in = in & i0 & i1 & i2 & (i3 | (nv <= 3));
-                    if (nv > 4) {                           // clipped polygons with 5+ vertices are rare
-                        const QuadRec *q = ta.quads + s_id[j];
-                        for (int i = 4; i < nv; ++i) {
-                            const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
-                            const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
-                            in = in & (front ? cr > 0 : cr < 0);
-                        }
+                auto d2 = [](uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); };
+                auto inner = [&](const uint4 &a, const uint4 &b) {       // staged edges: inner side is > 0
+                    const double ax = dpx - d2(a.x, a.y), ay = dpy - d2(a.z, a.w);
+                    return ax * d2(b.z, b.w) - ay * d2(b.x, b.y) > 0;
+                };
+                if (em & 1) in = in & inner(ea0, eb0);
+                if (em & 2) in = in & inner(ea1, eb1);
+                if (em & 4) in = in & inner(ea2, eb2);
+                if (em & 8) in = in & inner(ea3, eb3);
+                if (em & 16) {                              // clipped polygons with 5+ vertices are rare
+                    const QuadRec *q = ta.quads + s_id[j];
+                    for (int i = 4; i < nv; ++i) {
+                        const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
+                        const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
+                        in = in & (front ? cr > 0 : cr < 0);
                     }
                 }
                 const unsigned long long m = __ballot(in);
                 if (!m) continue;
                 qfrags += (unsigned int)__popcll(m);
+                bool pass = true;
+                if (!((allpass >> j) & 1)) {
                 // Depth of the quad at the sample and the test against the z-buffer
                 // (obj/triangular.py:351-360): zq = two_nf / (f_plus_n + (t / nz) * f_minus_n) with
                 // t the plane's value at the sample.  The reference's value needs two IEEE divisions;
@@ -425,18 +465,17 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                 // to its pole (or something is not finite); only then is the exactly rounded
                 // expression evaluated.  t itself is computed exactly as the reference does.
                 // Decisions stay bit-exact.
-                const uint4 p0 = rec[0], p1 = rec[1];
                 const double q_nx = __hiloint2double((int)p0.y, (int)p0.x), q_ny = __hiloint2double((int)p0.w, (int)p0.z);
                 const double nzq = __hiloint2double((int)p1.y, (int)p1.x), q_d = __hiloint2double((int)p1.w, (int)p1.z);
                 const double t = (q_nx * dpx + q_ny * dpy) + q_d;
-                const double a0 = fc.f_plus_n * nzq, b0 = fc.two_nf * nzq;      // per quad
+                const double a0 = d2(p3.x, p3.y), b0 = d2(p3.z, p3.w);          // f_plus_n * nz, two_nf * nz (staging)
                 const double tf = t * fc.f_minus_n;
                 const double den = a0 + tf;
                 const double prod = zbest * den;
                 const double e = prod - b0;
                 // an empty z-buffer entry (+-inf) beats or loses against every finite depth
                 const bool zinf = fabs(zbest) == INFINITY;
-                bool pass = zinf ? (rh ? zbest > 0 : zbest < 0) : (rh ? ((e > 0) == (den > 0)) : ((e < 0) == (den > 0)));
+                pass = zinf ? (rh ? zbest > 0 : zbest < 0) : (rh ? ((e > 0) == (den > 0)) : ((e < 0) == (den > 0)));
                 const bool clear = zinf || fabs(e) > 1e-9 * (fabs(prod) + fabs(b0));
                 const bool unsure = in && !(clear && fabs(den) > 2e-4 * (fabs(a0) + fabs(tf)));
                 if (__ballot(unsure)) {
@@ -445,12 +484,15 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                         pass = rh ? (zbest >= z) : (zbest <= z);
                     }
                 }
+                }
                 pass = pass && in;
                 qupd += (unsigned int)__popcll(__ballot(pass));
                 sten += pass ? (front ? 1 : -1) : 0;
             }
         }
     }
+
+    const unsigned long long t_quads = __builtin_amdgcn_s_memrealtime();
 
     // ---- 4. deferred shading + finalise (kernels_shade.h; obj/core.py:640)
     const bool lit = (int16_t)sten == 0;                  // the reference's buffer is int16
@@ -503,15 +545,14 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         rec[5] = n_small_raw; rec[6] = n_big_raw; rec[7] = n_quad_raw;
         rec[8] = (uint32_t)t_start;
         rec[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        rec[10] = rec[11] = 0;
+        rec[10] = (uint32_t)t_raster; rec[11] = (uint32_t)t_quads;
         if (n_small_raw > ta.cap[0]) { atomicOr(&ta.ctr->overflow, 1u); atomicMax(&ta.ctr->max_list[0], n_small_raw); }
         if (n_big_raw > ta.cap[1]) { atomicOr(&ta.ctr->overflow, 2u); atomicMax(&ta.ctr->max_list[1], n_big_raw); }
         if (n_quad_raw > ta.cap[2]) { atomicOr(&ta.ctr->overflow, 4u); atomicMax(&ta.ctr->max_list[2], n_quad_raw); }
     }
     if (tid < BIN_CLASSES) ta.bin_count[tid * n_tiles + tile] = 0;   // cursors zeroed for the next frame
     if (tid == 0) {                                       // what the slot's next frame should know about this tile
-        const uint32_t cost = tile_cost(n_small_raw, n_big_raw, n_quad_raw);
-        const int cls = cost >= 480u ? 0 : cost >= 240u ? 1 : cost >= 120u ? 2 : -1;
+        const int cls = cost >= 900u ? 0 : cost >= 400u ? 1 : cost >= 150u ? 2 : -1;
         uint8_t flag = 0;
         if (cls >= 0) {
             const uint32_t at = atomicAdd(&ta.next_hist->count[cls], 1u);

@@ -119,7 +119,7 @@ struct FrameSlot {
     mr::Counters *ctr(uint64_t frame) const { return d_counters.as<mr::Counters>() + (frame & 1); }
 };
 
-constexpr int MAX_SLOTS = 16;
+constexpr int MAX_SLOTS = 32;
 
 }  // namespace
 
@@ -840,7 +840,7 @@ int mr_render_device(mr_scene *sc, const mr_frame_desc *fr, void *d_out_rgb, voi
     if (rc) return rc;
     if ((rc = ensure_init())) return rc;
     FrameSlot *fs = slot_for(sc, stream ? (hipStream_t)stream : g_stream);
-    if (!fs) return fail(MR_E_INVALID, "a scene can be rendered from at most 16 different streams");
+    if (!fs) return fail(MR_E_INVALID, "a scene can be rendered from at most 32 different streams");
     return enqueue_frame(sc, fs, fr, static_cast<uint8_t *>(d_out_rgb));
 }
 

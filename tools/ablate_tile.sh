@@ -1,0 +1,16 @@
+#!/bin/bash
+# GPU box: VALU instruction count and time of k_tile with one phase removed (diagnostic builds from tools/_ablate)
+cd $GRAFT_REPO_ROOT
+cp py-numpy-renderer_amd/libmi355rast.so /tmp/lib_orig.so
+for k in 0 1 2 3 4; do
+  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -DMR_ABLATE=$k -o py-numpy-renderer_amd/libmi355rast.so tools/_ablate/csrc/mi355rast.hip || exit 1
+  echo "== ablate $k (0 none, 1 shade, 2 quads, 3 small pairs, 4 big pairs)"
+  bash tools/prof_pmc.sh abl$k k_tile SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY
+  python3 - <<'PY'
+import csv, glob
+f = sorted(glob.glob("gpurun_out/pmc/abl*/*/*_kernel_trace.csv"), key=lambda p: __import__("os").path.getmtime(p))[-1]
+d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "k_tile" in r["Kernel_Name"]]
+print("k_tile us:", [round(x / 1e3, 1) for x in d])
+PY
+done
+cp /tmp/lib_orig.so py-numpy-renderer_amd/libmi355rast.so

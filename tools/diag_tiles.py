@@ -19,8 +19,12 @@ small, big, quads = r[:, 5], r[:, 6], r[:, 7]
 print("tiles", len(r), "kernel span us", (end.max() - t0) * 10e-3, "sum dur us", dur.sum(), "mean", dur.mean(), "max", dur.max())
 print("list sizes: small max", small.max(), "sum", small.sum(), "| big max", big.max(), "sum", big.sum(), "| quads max", quads.max(), "sum", quads.sum())
 order = np.argsort(-dur)[:8]
+tr, tq = (r[:, 10] - start) * 10e-3, (r[:, 11] - r[:, 10]) * 10e-3
+ts = (end - r[:, 11]) * 10e-3
 for i in order:
-    print(f"  tile {i}: dur {dur[i]:.1f} us start +{(start[i]-t0)*10e-3:.1f} small {small[i]} big {big[i]} quads {quads[i]}")
+    print(f"     wave1: survivors {r[i,1]} allpass {r[i,2]} hits {r[i,4]}")
+    print(f"  tile {i}: dur {dur[i]:.1f} us start +{(start[i]-t0)*10e-3:.1f} small {small[i]} big {big[i]} quads {quads[i]} | raster {tr[i]:.1f} quads {tq[i]:.1f} shade {ts[i]:.1f}")
+print("phase sums (ms): raster", tr.sum() / 1e3, "quads", tq.sum() / 1e3, "shade+epilogue", ts.sum() / 1e3)
 for lo, hi in ((0, 1), (1, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 1000)):
     m = (dur >= lo) & (dur < hi)
     print(f"  dur [{lo},{hi}) us: {m.sum()} tiles, sum {dur[m].sum():.0f} us, mean small {small[m].mean() if m.any() else 0:.1f} big {big[m].mean() if m.any() else 0:.1f} quads {quads[m].mean() if m.any() else 0:.1f}")
