@@ -16,7 +16,7 @@ finalise to uint8, with the scene already resident in HBM and the frame left in 
 (``mr_render_device``).  A STEP is a batch of ``--frames-per-step`` (default 256) frames, so that the
 timed region is about half a second whatever --steps is; successive frames use DIFFERENT per-frame
 constants (the camera swings through 8 slightly different views), and ``--frames-in-flight``
-(default 4) of them are in flight on separate HIP streams.  With N > 1 every rank renders its share
+(default 3) of them are in flight on separate HIP streams.  With N > 1 every rank renders its share
 of the screen tiles (interleaved tile rows by default, ``--partition bands`` for contiguous row
 bands) and ONE RCCL all-gather assembles the frame on every rank (fixed total work -> "strong").
 
@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=256, help="frames in one step (a step is a batch of frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-marks", action="store_true", help="time every stage (5 event marks per frame instead of 3)")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="successive frames rendered on this many HIP streams (1 = one frame at a time)")
     ap.add_argument("--partition", choices=("stripes", "bands"), default="stripes",
                     help="screen-tile split for --gpus > 1: interleaved tile rows or contiguous row bands")
@@ -169,9 +169,11 @@ def main():
         partition = "stripes"
 
     def renderer(in_flight, light):
+        # one frame in 13 carries HIP event marks (frame + tile kernel, or every stage with --all-marks):
+        # a mark costs ~5 us between two kernels; 13 is coprime to the number of views and streams
         scene.camera, scene.debug_camera = base_cameras
         return BandRenderer(scene, rank, world, shadows=shadows, light_timing=light,
-                            frames_in_flight=in_flight, partition=partition)
+                            frames_in_flight=in_flight, partition=partition, timing_every=13)
 
     br = renderer(args.frames_in_flight, not args.all_marks)
 
@@ -233,7 +235,7 @@ def main():
         elapsed = float(t.item())
     n_frames = args.steps * fps
     assert br.verify(), "a work list overflowed in the timed frames"
-    ktimes, n_avg = backend.kernel_times(min(n_frames, 256))
+    ktimes, n_avg = br.kernel_times(64)
     last_frame = br.frame
 
     # the frame every rank now holds must be the frame a single device renders for that view
@@ -265,7 +267,7 @@ def main():
     solo = renderer(1, False)                                        # one frame at a time, every stage marked
     solo.set_descriptors(descriptors(False, False))
     per_frame_solo = timed(solo, n_side)
-    ktimes_solo, _ = backend.kernel_times(min(n_side, 64))
+    ktimes_solo, _ = solo.kernel_times(64)
     counted = renderer(args.frames_in_flight, True)                  # fragment counters on: no depth cull of quads
     counted.set_descriptors(descriptors(True, True))
     per_frame_counted = timed(counted, n_side)

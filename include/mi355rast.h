@@ -54,6 +54,8 @@ enum {
                                  the frame is the contract and the library skips work that cannot change it
                                  (shadow quads that cannot pass the depth test anywhere in a strip of pixels);
                                  mr_render sets it by itself when it is handed a stats pointer. */
+    MR_FRAME_NO_TIMING = 128, /* record no HIP events at all for this frame (each one costs a few microseconds between
+                                 two kernels): mr_stats.gpu_ms_* read 0 and mr_get_kernel_times skips the frame */
     MR_FRAME_KEEP_BUFFERS = 64 /* also write the reference's working buffers (z_buffer, stencil_buffer, winner
                                  face per pixel; obj/core.py:588-591) to device memory for mr_read_z /
                                  mr_read_stencil / mr_read_winner.  Without it they only ever exist on chip,
@@ -200,7 +202,8 @@ int mr_render_device(mr_scene *scene, const mr_frame_desc *frame, void *d_out_rg
 int mr_get_stats(mr_scene *scene, mr_stats *stats);
 
 /* Average device time in milliseconds (HIP events on the stream the kernels ran on) of each
- * stage over the last n_frames frames, most recent first; at most 64 per stream are remembered.
+ * stage over the most recent frames that carry event marks (at most n_frames of them; 64 frames per
+ * stream are remembered, frames rendered with MR_FRAME_NO_TIMING are skipped).
  *   [0] k_vertex_mfma (0 unless MR_VERTEX_PATH=mfma)   [1] k_setup   [2] k_bin_work   [3] k_tile
  *   [4] whole frame (start -> after k_tile)
  * Frames rendered with MR_FRAME_LIGHT_TIMING report [0..1] as 0 and [2] as the span from the start of
@@ -208,6 +211,8 @@ int mr_get_stats(mr_scene *scene, mr_stats *stats);
  * Synchronises the device.  Returns the number of frames averaged or a negative error. */
 #define MR_N_KERNEL_TIMES 5
 int mr_get_kernel_times(mr_scene *scene, int n_frames, float *out_ms, int cap);
+/* The same over the frames enqueued on ONE stream (as passed to mr_render_device; NULL = the library's own). */
+int mr_get_stream_kernel_times(mr_scene *scene, void *stream, int n_frames, float *out_ms, int cap);
 
 /* Debug taps for parity tests: the reference's working buffers after the last render
  * (obj/core.py:588-591).  Row = screen y (not flipped), as in the reference. */

@@ -20,6 +20,7 @@ MR_OK = 0
 MR_E_OVERFLOW = -4
 FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SKYBOX, FRAME_COUNTERS = 1, 2, 4, 8, 16, 32
 FRAME_KEEP_BUFFERS = 64
+FRAME_NO_TIMING = 128
 ABI_VERSION = 2
 TILE_RECORD_WORDS = 12
 
@@ -80,6 +81,7 @@ _PROTOTYPES = {
     "mr_render_device": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p]),
     "mr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mr_get_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "mr_get_stream_kernel_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "mr_read_z": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_stencil": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_winner": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -94,6 +96,26 @@ EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 _lib = None
 
 
+def _prefer_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own ``libamdhip64.so``; ``multigpu.py`` hands
+    torch's streams and tensors to this library, so both must run on the same copy.  Whichever copy is
+    loaded first serves both (same SONAME) -- but a torch imported AFTER the system copy finds no
+    device.  So when torch is installed its copy is loaded first, without importing torch itself."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass                                    # no torch, or not a ROCm build: the system runtime serves
+
+
 def load_library():
     """Load the HIP library; raises RuntimeError (never falls back) when it is not built."""
     global _lib
@@ -101,6 +123,7 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                                "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _prefer_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(lib, name)
@@ -129,13 +152,14 @@ def stripe_out_rows(height, stripe_count):
 
 
 def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False, counters=False,
-                    keep_buffers=False, stripe=None):
+                    keep_buffers=False, stripe=None, no_timing=False):
     d = FrameDesc()
     d.width, d.height, d.system = pf.width, pf.height, pf.system
     d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
     d.flags = ((FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
                | (FRAME_LIGHT_TIMING if light_timing else 0) | (FRAME_FACE_STATUS if face_status else 0)
-               | (FRAME_COUNTERS if counters else 0) | (FRAME_KEEP_BUFFERS if keep_buffers else 0))
+               | (FRAME_COUNTERS if counters else 0) | (FRAME_KEEP_BUFFERS if keep_buffers else 0)
+               | (FRAME_NO_TIMING if no_timing else 0))
     d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
     if stripe is not None:                      # (index, count): interleaved tile rows, see mi355rast.h
         d.stripe_index, d.stripe_count = int(stripe[0]), int(stripe[1])
@@ -230,7 +254,7 @@ class DeviceRenderer:
 
     # -- frames ---------------------------------------------------------------------------
     def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False, counters=True,
-               keep_buffers=None, stripe=None):
+               keep_buffers=None, stripe=None, timing=True):
         """``mr_render``: returns the uint8 rows ``(rows, W, 3)`` as a NumPy array.
 
         ``counters=True`` (``MR_FRAME_COUNTERS``) also keeps the reference-equivalent fragment
@@ -241,14 +265,16 @@ class DeviceRenderer:
         frame is asked for, those buffers never leave the chip, and shadow quads that cannot pass
         the depth test are skipped (``last_stats`` then reports the fragment counters as -1).
         ``stripe=(index, count)`` renders the interleaved tile rows of one device of a
-        multi-GPU split; the rows come back in the striped layout (``multigpu.unstripe``)."""
+        multi-GPU split; the rows come back in the striped layout (``multigpu.unstripe``).
+        ``timing=False`` (``MR_FRAME_NO_TIMING``) records no HIP events: each one costs a few
+        microseconds between two kernels; ``last_stats['gpu_ms_*']`` are then 0."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
         if keep_buffers is None:
             keep_buffers = counters
         desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status, counters=counters,
-                               keep_buffers=keep_buffers, stripe=stripe)
+                               keep_buffers=keep_buffers, stripe=stripe, no_timing=not timing)
         self._n_faces = sum(len(m._faces) for m in scene.models)
         rows = desc.row_end - desc.row_begin if stripe is None else stripe_out_rows(pf.height, stripe[1])
         out = np.empty((rows, pf.width, 3), dtype=np.uint8)
@@ -262,17 +288,26 @@ class DeviceRenderer:
         return out
 
     def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False,
-                      counters=False, stripe=None):
+                      counters=False, stripe=None, no_timing=False):
         """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = pack_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters, stripe=stripe)
+        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters, stripe=stripe, no_timing=no_timing)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
         self._frame = (pf.height, pf.width)
         self._desc = desc
         return desc
+
+    @staticmethod
+    def with_timing(desc, mode):
+        """Copy of a frame descriptor with its event marks set to *mode*: "all" stages, "light" (frame +
+        tile kernel) or "none"."""
+        out = FrameDesc.from_buffer_copy(desc)
+        out.flags &= ~(FRAME_LIGHT_TIMING | FRAME_NO_TIMING)
+        out.flags |= {"all": 0, "light": FRAME_LIGHT_TIMING, "none": FRAME_NO_TIMING}[mode]
+        return out
 
     def enqueue(self, desc, d_out_ptr, stream_ptr=0):
         """Re-issue a prepared frame descriptor (no Python-side packing in the timed loop)."""
@@ -307,6 +342,13 @@ class DeviceRenderer:
         """Average per-stage device milliseconds over the last *n_frames* frames (syncs)."""
         buf = (C.c_float * 5)()
         n = _check(self.lib.mr_get_kernel_times(self.handle, int(n_frames), buf, 5), "mr_get_kernel_times")
+        return dict(zip(self.KERNEL_TIME_NAMES, (float(v) for v in buf))), n
+
+    def stream_kernel_times(self, stream_ptr, n_frames):
+        """The same over the marked frames of one stream; returns (dict, frames averaged)."""
+        buf = (C.c_float * 5)()
+        n = _check(self.lib.mr_get_stream_kernel_times(self.handle, C.c_void_p(stream_ptr), int(n_frames), buf, 5),
+                   "mr_get_stream_kernel_times")
         return dict(zip(self.KERNEL_TIME_NAMES, (float(v) for v in buf))), n
 
     # -- debug taps -----------------------------------------------------------------------

@@ -353,7 +353,7 @@ class Scene:
         report = self.verbose and row_band is None
         overlay = self.draw_debug_frustum and row_band is None
         out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, keep_float=overlay,
-                             counters=False, keep_buffers=overlay)
+                             counters=False, keep_buffers=overlay, timing=False)
         self.last_stats = backend.last_stats
         if report:
             self._print_face_report(backend.read_face_status())

@@ -240,6 +240,7 @@ struct SetupArgs {
     int32_t *sil_edges;              // (quad_cap, 2): face, corner of each silhouette edge
     QuadRec *quads;
     uint32_t quad_cap;
+    uint32_t *clear4;                // four words this launch clears for the frame's tile kernel (its tile-history counts)
 };
 
 // One face: status, TriRec / TriAttr / TriClip.  Returns bit 0 = the face goes on to the tile
@@ -746,6 +747,7 @@ template <bool PRE_XFORM>
 __global__ void __launch_bounds__(SETUP_BLOCK, 4)
 k_setup(const FrameConst fc, const SetupArgs sa, const BinArgs bins, uint32_t face_blocks)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 4) sa.clear4[threadIdx.x] = 0;    // a memset would be a launch of its own
     if (blockIdx.x < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, blockIdx.x);
     else edge_block(fc, sa, bins, blockIdx.x - face_blocks);
 }

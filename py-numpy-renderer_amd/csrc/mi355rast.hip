@@ -94,6 +94,7 @@ struct FrameSlot {
 
     mr::Counters *h_counters = nullptr;           // pinned
     hipEvent_t ev_ring[EVENT_RING][N_MARKS] = {};
+    uint8_t ev_marks[EVENT_RING] = {};            // 0: the frame recorded no events, 1: frame + tile kernel, 2: every stage
     hipEvent_t *ev = ev_ring[0];
     uint64_t frames_enqueued = 0;
     bool events_ok = false;
@@ -442,9 +443,11 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     fs->ev = fs->ev_ring[fs->frames_enqueued % EVENT_RING];
 
     Counters *ctr = fs->ctr(fs->frames_enqueued), *next_ctr = fs->ctr(fs->frames_enqueued + 1);
-    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the tile kernel
-    const bool all_marks = !(fc.flags & MR_FRAME_LIGHT_TIMING);
-    HIP_TRY(hipEventRecord(fs->ev[0], stream));
+    // MR_FRAME_LIGHT_TIMING keeps only the marks around the frame and the tile kernel, MR_FRAME_NO_TIMING none
+    const bool timing = !(fc.flags & MR_FRAME_NO_TIMING);
+    const bool all_marks = timing && !(fc.flags & MR_FRAME_LIGHT_TIMING);
+    fs->ev_marks[fs->frames_enqueued % EVENT_RING] = timing ? (all_marks ? 2 : 1) : 0;
+    if (timing) HIP_TRY(hipEventRecord(fs->ev[0], stream));
     // The list cursors are left zeroed by k_tile and the frame counters are cleared by the previous
     // frame's k_tile, so a steady-state frame issues no memset; only a new tile grid needs one.
     HIP_TRY(fs->d_hist.ensure(2 * sizeof(TileHistory)));
@@ -457,8 +460,9 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     }
     const unsigned par = (unsigned)(fs->frames_enqueued & 1);
     TileHistory *hist = fs->d_hist.as<TileHistory>() + par, *next_hist = fs->d_hist.as<TileHistory>() + (par ^ 1u);
-    // this frame's tile kernel fills next_hist; its counts are cleared first (the previous frame is done reading it)
-    HIP_TRY(hipMemsetAsync(next_hist->count, 0, sizeof(next_hist->count), stream));
+    // this frame's tile kernel fills next_hist; its counts are cleared first, by k_setup (the previous
+    // frame is done reading it)
+    static_assert(sizeof(next_hist->count) == 16, "k_setup clears four words");
 
     BinArgs ba;
     ba.tris = fs->d_tris.as<TriRec>(); ba.quads = fs->d_quads.as<QuadRec>();
@@ -475,6 +479,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.status = fs->d_status.as<uint8_t>(); sa.count_list = fs->d_count_list.as<uint32_t>(); sa.ctr = ctr;
     sa.edges = sc->d_edges.as<EdgeRec>(); sa.edge_inc = sc->d_edge_inc.as<uint32_t>(); sa.face_n = sc->d_face_n.as<double>();
     sa.sil_edges = fs->d_sil.as<int32_t>(); sa.quads = fs->d_quads.as<QuadRec>(); sa.quad_cap = fs->quad_cap;
+    sa.clear4 = next_hist->count;
 
     // ---- 1. set-up: faces and (with shadows) edges, one launch
     if (vertex_mfma && fc.n_vertices > 0)
@@ -489,6 +494,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                 hipLaunchKernelGGL(k_setup<true>, dim3(face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
             else
                 hipLaunchKernelGGL(k_setup<false>, dim3(face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
+        } else {
+            HIP_TRY(hipMemsetAsync(next_hist->count, 0, sizeof(next_hist->count), stream));
         }
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
@@ -502,7 +509,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                            fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(),
                            fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), ctr, count_blocks);
     }
-    HIP_TRY(hipEventRecord(fs->ev[3], stream));
+    if (timing) HIP_TRY(hipEventRecord(fs->ev[3], stream));
 
     // ---- 3. tiles: coverage, z, stencil, shading, finalise
     TileArgs ta;
@@ -528,7 +535,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         hipLaunchKernelGGL(k_tile, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
     else          // nothing to draw on this device (a stripe beyond the frame): still hand the counters on
         HIP_TRY(hipMemsetAsync(next_ctr, 0, sizeof(Counters), stream));
-    HIP_TRY(hipEventRecord(fs->ev[4], stream));
+    if (timing) HIP_TRY(hipEventRecord(fs->ev[4], stream));
     if ((fc.flags & MR_FRAME_FACE_STATUS) && fc.n_faces > 0)
         hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
                            fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(), fs->d_clips.as<TriClip>(),
@@ -577,11 +584,12 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
     s.tri_bin_entries = c.tri_bin_total; s.quad_bin_entries = c.bin_total - c.tri_bin_total;
     sc->n_silhouette = (int)c.n_quads;
     float ms = 0;
-    auto span = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, fs->ev[a], fs->ev[b]); return ms; };
+    const bool timed = !(fs->last_frame.flags & MR_FRAME_NO_TIMING);
+    auto span = [&](int a, int b) { ms = 0; if (timed) (void)hipEventElapsedTime(&ms, fs->ev[a], fs->ev[b]); return ms; };
     const bool light = (fs->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
     s.gpu_ms_setup = light ? 0.f : span(0, 2); s.gpu_ms_binning = light ? span(0, 3) : span(2, 3);
     s.gpu_ms_tile = span(3, 4);
-    s.gpu_ms_copy = with_copy ? span(4, 5) : 0.f;
+    s.gpu_ms_copy = with_copy && timed ? span(4, 5) : 0.f;
     s.gpu_ms_total = span(0, with_copy ? 5 : 4);
     bool grown = false;
     if (c.overflow) {
@@ -821,7 +829,7 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
         if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
         if ((rc = fetch_counters(sc, fs))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipEventRecord(fs->ev[5], g_stream));
+        if (!(fr->flags & MR_FRAME_NO_TIMING)) HIP_TRY(hipEventRecord(fs->ev[5], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         rc = collect(sc, fs, true);
         if (rc == MR_OK) {
@@ -866,6 +874,31 @@ int mr_get_stats(mr_scene *sc, mr_stats *stats)
     return MR_OK;
 }
 
+namespace {
+// adds the marked frames of one slot (most recent first, at most `limit`) to acc; returns how many
+uint64_t add_slot_times(const FrameSlot &s, uint64_t limit, double acc[MR_N_KERNEL_TIMES])
+{
+    const uint64_t have = std::min<uint64_t>(s.frames_enqueued, EVENT_RING);
+    uint64_t taken = 0;
+    for (uint64_t i = 0; i < have && taken < limit; ++i) {
+        const uint64_t slot = (s.frames_enqueued - 1 - i) % EVENT_RING;
+        const int marks = s.ev_marks[slot];
+        if (!marks) continue;
+        const hipEvent_t *ev = s.ev_ring[slot];
+        auto span = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return (double)ms; };
+        if (marks == 1) {
+            acc[2] += span(0, 3);
+        } else {
+            acc[0] += span(0, 1); acc[1] += span(1, 2); acc[2] += span(2, 3);
+        }
+        acc[3] += span(3, 4);
+        acc[4] += span(0, 4);
+        ++taken;
+    }
+    return taken;
+}
+}  // namespace
+
 int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
 {
     if (!sc || !out_ms || cap < MR_N_KERNEL_TIMES) return fail(MR_E_INVALID, "need room for MR_N_KERNEL_TIMES floats");
@@ -873,35 +906,34 @@ int mr_get_kernel_times(mr_scene *sc, int n_frames, float *out_ms, int cap)
     HIP_TRY(hipDeviceSynchronize());
     double acc[MR_N_KERNEL_TIMES] = {};
     uint64_t used = 0;
-    // only the slots that render the same kind of frame as the most recent one (same flags and
-    // row band) are averaged: a whole-frame mr_render on the library's stream must not be mixed
-    // into the statistics of band frames enqueued on the caller's streams
+    // only the slots that render the same kind of frame as the most recent one (same flags apart from
+    // the timing bits, same rows) are averaged: a whole-frame mr_render on the library's stream must
+    // not be mixed into the statistics of band frames enqueued on the caller's streams
     const mr_frame_desc &ref = sc->last->last_frame;
+    constexpr int timing_bits = MR_FRAME_NO_TIMING | MR_FRAME_LIGHT_TIMING;
     auto same_kind = [&](const FrameSlot &s) {
-        return s.have_frame && s.last_frame.flags == ref.flags && s.last_frame.row_begin == ref.row_begin &&
-               s.last_frame.row_end == ref.row_end && s.last_frame.stripe_count == ref.stripe_count &&
-               s.last_frame.stripe_index == ref.stripe_index;
+        return s.have_frame && (s.last_frame.flags & ~timing_bits) == (ref.flags & ~timing_bits) &&
+               s.last_frame.row_begin == ref.row_begin && s.last_frame.row_end == ref.row_end &&
+               s.last_frame.stripe_count == ref.stripe_count && s.last_frame.stripe_index == ref.stripe_index;
     };
     int active = 0;
     for (auto &s : sc->slots) active += same_kind(*s) ? 1 : 0;
     const uint64_t per_slot = std::max<uint64_t>(1, ((uint64_t)std::max(n_frames, 1) + active - 1) / std::max(active, 1));
-    for (auto &s : sc->slots) {
-        if (!same_kind(*s)) continue;
-        const bool light = (s->last_frame.flags & MR_FRAME_LIGHT_TIMING) != 0;
-        const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(s->frames_enqueued, EVENT_RING), per_slot);
-        for (uint64_t i = 0; i < n; ++i) {
-            hipEvent_t *ev = s->ev_ring[(s->frames_enqueued - 1 - i) % EVENT_RING];
-            auto span = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return (double)ms; };
-            if (light) {
-                acc[2] += span(0, 3);
-            } else {
-                acc[0] += span(0, 1); acc[1] += span(1, 2); acc[2] += span(2, 3);
-            }
-            acc[3] += span(3, 4);
-            acc[4] += span(0, 4);
-        }
-        used += n;
-    }
+    for (auto &s : sc->slots)
+        if (same_kind(*s)) used += add_slot_times(*s, per_slot, acc);
+    for (int k = 0; k < MR_N_KERNEL_TIMES; ++k) out_ms[k] = used ? (float)(acc[k] / (double)used) : 0.f;
+    return (int)used;
+}
+
+int mr_get_stream_kernel_times(mr_scene *sc, void *stream, int n_frames, float *out_ms, int cap)
+{
+    if (!sc || !out_ms || cap < MR_N_KERNEL_TIMES) return fail(MR_E_INVALID, "need room for MR_N_KERNEL_TIMES floats");
+    const hipStream_t want = stream ? (hipStream_t)stream : g_stream;
+    HIP_TRY(hipDeviceSynchronize());
+    double acc[MR_N_KERNEL_TIMES] = {};
+    uint64_t used = 0;
+    for (auto &s : sc->slots)
+        if (s->stream == want && s->have_frame) used += add_slot_times(*s, (uint64_t)std::max(n_frames, 1), acc);
     for (int k = 0; k < MR_N_KERNEL_TIMES; ++k) out_ms[k] = used ? (float)(acc[k] / (double)used) : 0.f;
     return (int)used;
 }

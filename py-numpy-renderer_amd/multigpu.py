@@ -92,7 +92,7 @@ class BandRenderer:
     """
 
     def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False, frames_in_flight=1,
-                 partition="bands"):
+                 partition="bands", timing_every=1):
         height, width = (int(v) for v in scene.resolution)
         if partition not in ("bands", "stripes"):
             raise ValueError(f"unknown partition {partition!r}")
@@ -100,6 +100,9 @@ class BandRenderer:
         self.height, self.width = height, width
         self.backend = scene._backend()
         self.scene, self.shadows, self.light_timing = scene, shadows, light_timing
+        # HIP event marks cost a few microseconds each between two kernels: only every timing_every-th
+        # frame carries them (0: none does); mr_get_kernel_times averages over those
+        self.timing_every = int(timing_every)
         striped = partition == "stripes" and world > 1
         self.stripe = (rank, world) if striped else None
         self.band = (0, height) if striped else row_band(height, rank, world)
@@ -115,6 +118,7 @@ class BandRenderer:
             self.lanes.append((stream, frame, part, gathered))
         self.index = unstripe_index(height, world, "cuda") if striped else None
         self.desc = None
+        self.descs, self.descs_untimed = [], []
         self.prime()
         self.frame = self.lanes[0][1]
 
@@ -129,18 +133,23 @@ class BandRenderer:
                                                            light_timing=self.light_timing, stripe=self.stripe)
                 stream.synchronize()
             if not self.backend.overflowed():
+                self.set_descriptors([self.desc])
                 return
         raise RuntimeError("work lists kept overflowing while priming")
 
     def set_descriptors(self, descs):
         """Frame descriptors to cycle through in ``step`` (e.g. a camera path), instead of repeating
         the priming frame's."""
-        self.descs = list(descs)
+        mode = "light" if self.light_timing else "all"
+        self.descs = [self.backend.with_timing(d, mode) for d in descs]
+        self.descs_untimed = [self.backend.with_timing(d, "none") for d in descs]
 
     def step(self):
         """Enqueue one frame (no host synchronisation); returns the tensor it will land in."""
         stream, frame, part, gathered = self.lanes[self.count % len(self.lanes)]
-        desc = self.descs[self.count % len(self.descs)] if self.descs else self.desc
+        timed = self.timing_every > 0 and self.count % self.timing_every == 0
+        pool = self.descs if timed else self.descs_untimed
+        desc = pool[self.count % len(pool)]
         self.count += 1
         with torch.cuda.stream(stream):
             self.backend.enqueue(desc, part.data_ptr(), stream.cuda_stream)
@@ -160,6 +169,17 @@ class BandRenderer:
             return True
         self.prime()
         return False
+
+    def kernel_times(self, n_frames=64):
+        """Average device milliseconds per stage over this renderer's own marked frames (at most *n_frames*
+        per stream); returns (dict, frames averaged).  Synchronises the device."""
+        total, used = {}, 0
+        for stream, *_ in self.lanes:
+            times, n = self.backend.stream_kernel_times(stream.cuda_stream, n_frames)
+            for k, v in times.items():
+                total[k] = total.get(k, 0.0) + v * n
+            used += n
+        return {k: (v / used if used else 0.0) for k, v in total.items()}, used
 
     def synchronize(self):
         for stream, *_ in self.lanes:
