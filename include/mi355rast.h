@@ -56,6 +56,9 @@ enum {
                                  mr_render sets it by itself when it is handed a stats pointer. */
     MR_FRAME_NO_TIMING = 128, /* record no HIP events at all for this frame (each one costs a few microseconds between
                                  two kernels): mr_stats.gpu_ms_* read 0 and mr_get_kernel_times skips the frame */
+    MR_FRAME_OVERLAY = 256,   /* replay the statement lists of mr_scene_set_overlay (the debug-camera frustum of
+                                 obj/core.py:638) on the frame after the tile kernel; implies MR_FRAME_KEEP_BUFFERS
+                                 and MR_FRAME_KEEP_FLOAT; whole frames only (no row band, no stripes) */
     MR_FRAME_KEEP_BUFFERS = 64 /* also write the reference's working buffers (z_buffer, stencil_buffer, winner
                                  face per pixel; obj/core.py:588-591) to device memory for mr_read_z /
                                  mr_read_stencil / mr_read_winner.  Without it they only ever exist on chip,
@@ -158,7 +161,7 @@ int mr_device_available(void);
 int mr_abi_version(void);
 
 /* sizeof() of the ABI structs as this build sees them (0 mr_frame_desc, 1 mr_material,
- * 2 mr_model_desc, 3 mr_stats; -1 otherwise), so a binding can verify its own layout. */
+ * 2 mr_model_desc, 3 mr_stats, 4 mr_overlay_desc; -1 otherwise), so a binding can verify its own layout. */
 int mr_abi_struct_size(int which);
 
 /* Scene() -- obj/core.py:563-582.  Returns NULL on failure. */
@@ -187,10 +190,35 @@ int mr_scene_clear(mr_scene *scene);
  * mr_render / mr_get_stats as MR_E_OVERFLOW internally and rendered again); this only sets where they start. */
 int mr_scene_set_list_capacities(mr_scene *scene, uint32_t small_pairs, uint32_t big_pairs, uint32_t quads, uint32_t work);
 
+/* The debug-camera frustum overlay (obj/core.py:638; obj/frustums.py:46-103; obj/line.py:6-16) as flat
+ * statement lists.  The host walks the frustum's edges (float64 DDA) segment by segment; every kept point
+ * of a segment performs the reference's writes in the reference's order: centre (z and red), then for step
+ * -1 and +1: z into the row neighbour, z into the column neighbour, half blend into the row neighbour, half
+ * blend into the column neighbour.  target / next are (5, n_points) row-major: per target set (centre,
+ * row-1, col-1, row+1, col+1) the linear pixel index row * width + col (row = screen y, not flipped) and
+ * the index of the next point OF THE SAME SEGMENT with the same target (-1: none; NumPy's "last one wins").
+ * touched lists every pixel any statement writes, once.  Pointers are read during the call only.
+ * NULL (or n_points == 0) removes the overlay.  Frames that set MR_FRAME_OVERLAY replay it. */
+typedef struct mr_overlay_desc {
+    int32_t n_segments, n_points, n_touched, reserved;
+    const int32_t *seg_first, *seg_count;   /* (n_segments) first point and number of points of each segment */
+    const int32_t *target;                  /* (5, n_points) */
+    const int32_t *next;                    /* (5, n_points) */
+    const double *z;                        /* (n_points) linearised depth of each point */
+    const int32_t *touched;                 /* (n_touched) */
+} mr_overlay_desc;
+int mr_scene_set_overlay(mr_scene *scene, const mr_overlay_desc *overlay);
+
 /* Scene.render() -- obj/core.py:587-640: depth/ambient pass, shadow-volume stencil pass, lit
  * pass and finalise (flip, **0.8, *255, uint8) on the GPU.  out_rgb receives
  * (row_end - row_begin) x width x 3 bytes, row 0 = top row of the band.  stats may be NULL. */
 int mr_render(mr_scene *scene, const mr_frame_desc *frame, uint8_t *out_rgb, mr_stats *stats);
+
+/* Page-locked host memory for mr_render's out_rgb (hipHostMalloc / hipHostFree): the device-to-host copy
+ * of the frame then runs at the full PCIe rate instead of being staged through the runtime's own buffers.
+ * Optional: mr_render accepts any host pointer.  mr_host_alloc returns NULL on failure. */
+void *mr_host_alloc(uint64_t bytes);
+void mr_host_free(void *p);
 
 /* Same, but leaves the uint8 band in device memory at d_out_rgb (a device pointer owned by
  * the caller, e.g. a torch tensor's data_ptr) and does not synchronise the host: work is

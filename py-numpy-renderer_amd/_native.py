@@ -7,6 +7,7 @@ GPU is visible the calls raise ``RuntimeError``.
 """
 import ctypes as C
 import os
+import zlib
 
 import numpy as np
 
@@ -21,6 +22,7 @@ MR_E_OVERFLOW = -4
 FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SKYBOX, FRAME_COUNTERS = 1, 2, 4, 8, 16, 32
 FRAME_KEEP_BUFFERS = 64
 FRAME_NO_TIMING = 128
+FRAME_OVERLAY = 256
 ABI_VERSION = 2
 TILE_RECORD_WORDS = 12
 
@@ -54,6 +56,12 @@ class ModelDesc(C.Structure):
                 ("vertices_are_f32", C.c_int32), ("clip", C.c_int32), ("depth_test", C.c_int32)]
 
 
+class OverlayDesc(C.Structure):
+    _fields_ = [("n_segments", C.c_int32), ("n_points", C.c_int32), ("n_touched", C.c_int32), ("reserved", C.c_int32),
+                ("seg_first", C.c_void_p), ("seg_count", C.c_void_p), ("target", C.c_void_p), ("next", C.c_void_p),
+                ("z", C.c_void_p), ("touched", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = ([(n, C.c_int64) for n in (
         "frag_tri", "frag_quad", "covered_px", "lit_px", "stencil_updates", "n_faces", "n_faces_setup",
@@ -76,8 +84,11 @@ _PROTOTYPES = {
     "mr_scene_set_skybox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_scene_add_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
     "mr_scene_clear": (C.c_int, [C.c_void_p]),
+    "mr_scene_set_overlay": (C.c_int, [C.c_void_p, C.POINTER(OverlayDesc)]),
     "mr_scene_set_list_capacities": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "mr_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "mr_host_free": (None, [C.c_void_p]),
     "mr_render_device": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p]),
     "mr_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mr_get_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),
@@ -130,7 +141,7 @@ def load_library():
             fn.restype, fn.argtypes = res, args
         if lib.mr_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_NAME}: ABI version {lib.mr_abi_version()}, this binding speaks {ABI_VERSION}; rebuild")
-        for which, struct in enumerate((FrameDesc, MaterialDesc, ModelDesc, Stats)):
+        for which, struct in enumerate((FrameDesc, MaterialDesc, ModelDesc, Stats, OverlayDesc)):
             if lib.mr_abi_struct_size(which) != C.sizeof(struct):
                 raise RuntimeError(f"{LIB_NAME}: layout of {struct.__name__} differs from the binding "
                                    f"({lib.mr_abi_struct_size(which)} vs {C.sizeof(struct)} bytes); rebuild")
@@ -152,22 +163,21 @@ def stripe_out_rows(height, stripe_count):
 
 
 def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, face_status=False, counters=False,
-                    keep_buffers=False, stripe=None, no_timing=False):
+                    keep_buffers=False, stripe=None, no_timing=False, overlay=False):
     d = FrameDesc()
     d.width, d.height, d.system = pf.width, pf.height, pf.system
     d.backface_culling, d.light_type = int(pf.backface_culling), pf.light_type
     d.flags = ((FRAME_SHADOWS if pf.shadows else 0) | (FRAME_KEEP_FLOAT if keep_float else 0)
                | (FRAME_LIGHT_TIMING if light_timing else 0) | (FRAME_FACE_STATUS if face_status else 0)
                | (FRAME_COUNTERS if counters else 0) | (FRAME_KEEP_BUFFERS if keep_buffers else 0)
-               | (FRAME_NO_TIMING if no_timing else 0))
+               | (FRAME_NO_TIMING if no_timing else 0) | (FRAME_OVERLAY if overlay else 0))
     d.row_begin, d.row_end = (0, pf.height) if row_band is None else (int(row_band[0]), int(row_band[1]))
     if stripe is not None:                      # (index, count): interleaved tile rows, see mi355rast.h
         d.stripe_index, d.stripe_count = int(stripe[0]), int(stripe[1])
     for name in ("mvp", "viewport", "debug_mvp", "frustum_planes", "camera_pos", "light_pos", "light_dir",
                  "light_color", "light_ambient"):
-        dst = getattr(d, name)
-        for i, v in enumerate(np.asarray(getattr(pf, name), dtype=np.float64).ravel()):
-            dst[i] = v
+        src = np.ascontiguousarray(getattr(pf, name), dtype=np.float64)
+        C.memmove(getattr(d, name), src.ctypes.data, src.nbytes)
     d.z_near, d.z_far = pf.z_near, pf.z_far
     d.specular_strength = pf.specular_strength
     d.att_constant, d.att_linear, d.att_quadratic = pf.att_constant, pf.att_linear, pf.att_quadratic
@@ -186,6 +196,39 @@ def fill_frame_desc(pf, row_band=None, keep_float=False, light_timing=False, fac
     return d
 
 
+class _PinnedPool:
+    """Page-locked output buffers for ``mr_render``, recycled when the NumPy array that wraps one is
+    garbage collected: a render loop that drops each frame before asking for the next allocates once."""
+
+    def __init__(self, lib, keep=4):
+        self.lib, self.keep = lib, keep
+        self.free = {}                       # bytes -> [pointers]
+
+    def array(self, shape):
+        import weakref
+        nbytes = int(np.prod(shape))
+        stock = self.free.setdefault(nbytes, [])
+        ptr = stock.pop() if stock else self.lib.mr_host_alloc(nbytes)
+        if not ptr:
+            return np.empty(shape, dtype=np.uint8)           # pageable memory still works, just slower
+        raw = (C.c_uint8 * nbytes).from_address(ptr)
+        arr = np.frombuffer(raw, dtype=np.uint8).reshape(shape)
+        weakref.finalize(raw, self._release, nbytes, ptr)       # raw lives as long as any view of arr does
+        return arr
+
+    def _release(self, nbytes, ptr):
+        stock = self.free.setdefault(nbytes, [])
+        if len(stock) < self.keep:
+            stock.append(ptr)
+        else:
+            self.lib.mr_host_free(ptr)
+
+    def close(self):
+        for stock in self.free.values():
+            while stock:
+                self.lib.mr_host_free(stock.pop())
+
+
 class DeviceRenderer:
     """Owns one ``mr_scene`` handle and keeps it in step with a Python ``Scene``."""
 
@@ -197,14 +240,31 @@ class DeviceRenderer:
             raise RuntimeError("mr_scene_create failed: " + self.lib.mr_last_error().decode())
         self._signature = None
         self._sky_key = None
-        self.last_stats = None
+        self._last_stats = {}
         self._frame = None
+        self._packed = (None, None)          # (key, PackedFrame) of the last frame's per-frame constants
+        self._pinned = _PinnedPool(self.lib)
 
     # -- scene upload ---------------------------------------------------------------------
     @staticmethod
-    def _scene_signature(scene):
-        return tuple((id(m), m._revision, id(m.vertices), id(m._faces), id(m.uv), id(m.normals),
-                      bool(m.clip), bool(m.depth_test)) for m in scene.models)
+    def _fingerprint(arr):
+        """Cheap identity of an array's CONTENT: where it lives, its layout, and a checksum of a strided
+        sample of ~64 elements (a few microseconds).  Catches replacement and wholesale in-place
+        edits; single-element pokes need ``Model.invalidate()``."""
+        if arr is None:
+            return None
+        a = np.asarray(arr)
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 64)
+        return (a.__array_interface__["data"][0], a.shape, a.dtype.str, zlib.crc32(np.ascontiguousarray(flat[::step])))
+
+    @classmethod
+    def _scene_signature(cls, scene):
+        from .materials import Material
+        return (Material.revision,) + tuple(
+            (id(m), m._revision, cls._fingerprint(m.vertices), cls._fingerprint(m._faces), cls._fingerprint(m.uv),
+             cls._fingerprint(m.normals), bool(m.clip), bool(m.depth_test), tuple(m.material_group))
+            for m in scene.models)
 
     def sync_scene(self, scene):
         sig = self._scene_signature(scene)
@@ -252,9 +312,55 @@ class DeviceRenderer:
             _check(self.lib.mr_scene_set_skybox(self.handle, tex.ctypes.data, tex.shape[1]), "mr_scene_set_skybox")
         self._sky_key = key
 
+    def sync_overlay(self, scene):
+        """Debug-frustum overlay (obj/core.py:638): the statement lists depend on the two cameras and the
+        resolution only (a camera's MVP is cached for life), so they are built and uploaded once."""
+        cam = scene.camera
+        dbg = scene.debug_camera if scene.debug_camera is not None else cam
+        key = (id(cam), id(dbg), id(cam.__dict__.get("MVP")), id(dbg.__dict__.get("MVP")), tuple(scene.resolution),
+               int(scene.system), int(scene.subsystem))
+        if getattr(self, "_overlay_key", None) == key:
+            return
+        from .frustums import OverlayOps
+        ops = OverlayOps(cam, dbg, scene.resolution)
+        d = OverlayDesc()
+        d.n_segments, d.n_points, d.n_touched = len(ops.seg_first), ops.n_points, len(ops.touched)
+        d.seg_first, d.seg_count = ops.seg_first.ctypes.data, ops.seg_count.ctypes.data
+        d.target, d.next, d.z, d.touched = (ops.target.ctypes.data, ops.next.ctypes.data, ops.z.ctypes.data,
+                                            ops.touched.ctypes.data)
+        _check(self.lib.mr_scene_set_overlay(self.handle, C.byref(d) if ops.n_points else None), "mr_scene_set_overlay")
+        self._overlay_key = (id(cam), id(dbg), id(cam.__dict__.get("MVP")), id(dbg.__dict__.get("MVP")),
+                             tuple(scene.resolution), int(scene.system), int(scene.subsystem))
+
     # -- frames ---------------------------------------------------------------------------
+    @staticmethod
+    def _frame_key(scene, shadows):
+        """Everything ``pack_frame`` reads, cheaply: the camera objects (their MVP is cached for life, as in
+        the reference) and the values of the few scalars and 3-vectors a caller may have reassigned."""
+        cam, light = scene.camera, scene.light
+        dbg = scene.debug_camera if scene.debug_camera is not None else cam
+
+        def vec(x):
+            return tuple(np.asarray(x, dtype=np.float64).ravel().tolist())
+        return (id(cam), id(dbg), id(cam.__dict__.get("MVP")), id(dbg.__dict__.get("MVP")), tuple(scene.resolution),
+                int(scene.system), int(scene.subsystem), bool(shadows), bool(cam.backface_culling), float(cam.near),
+                float(cam.far), cam.x_offset, cam.y_offset, vec(cam.position), id(light), vec(light.position),
+                vec(light.center), vec(light.color), vec(light.ambient), str(light.light_type),
+                float(light.specular_strength), float(light.constant), float(light.linear), float(light.quadratic),
+                id(scene.skybox) if scene.skybox is None or hasattr(scene.skybox, "textures") else vec(scene.skybox))
+
+    def packed_frame(self, scene, shadows):
+        """``pack_frame`` with a one-entry cache: a render loop that changes nothing between two frames does
+        not rebuild the matrices and planes (150 us of NumPy scalar arithmetic, more than the frame takes)."""
+        key = self._frame_key(scene, shadows)
+        if self._packed[0] != key or "MVP" not in scene.camera.__dict__:
+            self._pack_serial = getattr(self, "_pack_serial", 0) + 1
+            self._packed = (None, pack_frame(scene, shadows))
+            self._packed = (self._frame_key(scene, shadows), self._packed[1])    # the MVPs exist (and are cached) now
+        return self._packed[1]
+
     def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False, counters=True,
-               keep_buffers=None, stripe=None, timing=True):
+               keep_buffers=None, stripe=None, timing=True, overlay=False):
         """``mr_render``: returns the uint8 rows ``(rows, W, 3)`` as a NumPy array.
 
         ``counters=True`` (``MR_FRAME_COUNTERS``) also keeps the reference-equivalent fragment
@@ -267,32 +373,53 @@ class DeviceRenderer:
         ``stripe=(index, count)`` renders the interleaved tile rows of one device of a
         multi-GPU split; the rows come back in the striped layout (``multigpu.unstripe``).
         ``timing=False`` (``MR_FRAME_NO_TIMING``) records no HIP events: each one costs a few
-        microseconds between two kernels; ``last_stats['gpu_ms_*']`` are then 0."""
+        microseconds between two kernels; ``last_stats['gpu_ms_*']`` are then 0.
+        ``overlay=True`` (``MR_FRAME_OVERLAY``) draws the debug camera's frustum into the frame on the
+        device, as the reference's ``render()`` always does (obj/core.py:638)."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
-        pf = pack_frame(scene, shadows)
+        pf = self.packed_frame(scene, shadows)
+        if overlay:
+            self.sync_overlay(scene)
         if keep_buffers is None:
             keep_buffers = counters
-        desc = fill_frame_desc(pf, row_band, keep_float, face_status=face_status, counters=counters,
-                               keep_buffers=keep_buffers, stripe=stripe, no_timing=not timing)
+        dkey = (getattr(self, "_pack_serial", 0), row_band, keep_float, face_status, counters, keep_buffers, stripe, timing,
+                overlay)
+        if getattr(self, "_desc_key", None) != dkey:
+            self._desc_cached = fill_frame_desc(pf, row_band, keep_float, face_status=face_status, counters=counters,
+                                                keep_buffers=keep_buffers, stripe=stripe, no_timing=not timing,
+                                                overlay=overlay)
+            self._desc_key = dkey
+        desc = self._desc_cached
         self._n_faces = sum(len(m._faces) for m in scene.models)
         rows = desc.row_end - desc.row_begin if stripe is None else stripe_out_rows(pf.height, stripe[1])
-        out = np.empty((rows, pf.width, 3), dtype=np.uint8)
+        out = self._pinned.array((rows, pf.width, 3))
         stats = Stats()
         _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats) if counters else None),
                "mr_render")
-        if not counters:
-            _check(self.lib.mr_get_stats(self.handle, C.byref(stats)), "mr_get_stats")
-        self.last_stats = stats.as_dict()
+        # a frame rendered for the frame's sake fetches its statistics only if somebody looks at them
+        self._last_stats = stats.as_dict() if counters else None
         self._frame = (pf.height, pf.width)
         return out
+
+    @property
+    def last_stats(self):
+        if self._last_stats is None and self.handle:
+            st = Stats()
+            _check(self.lib.mr_get_stats(self.handle, C.byref(st)), "mr_get_stats")
+            self._last_stats = st.as_dict()
+        return self._last_stats
+
+    @last_stats.setter
+    def last_stats(self, value):
+        self._last_stats = value
 
     def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False,
                       counters=False, stripe=None, no_timing=False):
         """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
-        pf = pack_frame(scene, shadows)
+        pf = self.packed_frame(scene, shadows)
         desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters, stripe=stripe, no_timing=no_timing)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
@@ -394,6 +521,7 @@ class DeviceRenderer:
         if self.handle:
             self.lib.mr_scene_destroy(self.handle)
             self.handle = None
+            self._pinned.close()
 
     def __del__(self):  # best effort
         try:

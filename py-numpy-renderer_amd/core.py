@@ -158,6 +158,13 @@ class Model:
         self._revision += 1
         return self
 
+    def invalidate(self):
+        """Tell the renderer that ``vertices`` / ``uv`` / ``normals`` / ``_faces`` were edited IN PLACE.
+        Replacing an array, ``Model @ M``, ``textures.register`` and material assignments are noticed
+        by themselves, and so are in-place edits that change a sampled checksum of the arrays (scaling,
+        ``[:] =``); a change to a few single elements needs this call."""
+        self._revision += 1
+
     def face_material(self, group_index):
         """Material of a face whose first corner carries *group_index* (``obj/core.py:125``)."""
         return self.materials.get(self.material_group[group_index], self.materials["default"])
@@ -327,10 +334,14 @@ class Scene:
         self.skybox = skymap
         self.shadows = shadows
         self.device = device
-        self.draw_debug_frustum = False     # the reference always overlays it (core.py:638); opt-in here
+        self.draw_debug_frustum = True      # like the reference, which always overlays it (core.py:638); switchable here
         self.verbose = False                # the reference always prints its face histogram (core.py:634-636)
         self._renderer = None
-        self.last_stats = None
+
+    @property
+    def last_stats(self):
+        """Statistics of the last frame (``mr_stats``), fetched from the device when asked for."""
+        return None if self._renderer is None else self._renderer.last_stats
 
     def add_model(self, model):
         self.models.append(model)
@@ -346,25 +357,20 @@ class Scene:
         """Render one frame on the GPU and return ``uint8 (H, W, 3)`` (row 0 = top).
 
         Unlike the reference, repeated calls give the same frame: the silhouette is rebuilt
-        from scratch every frame instead of being toggled in ``model.silhouette``.  With
-        ``scene.verbose`` (off by default) the three lines the reference prints per model after
-        its lit pass (``obj/core.py:634-636``) are reproduced from the device's per-face codes."""
+        from scratch every frame instead of being toggled in ``model.silhouette``.  Like the
+        reference, the frame carries the debug camera's frustum as red lines (``obj/core.py:638``);
+        ``scene.draw_debug_frustum = False`` leaves it out.  With ``scene.verbose`` (off by default)
+        the three lines the reference prints per model after its lit pass (``obj/core.py:634-636``)
+        are reproduced from the device's per-face codes."""
         backend = self._backend()
         report = self.verbose and row_band is None
+        # the debug camera's frustum, drawn by the device into its own frame and z-buffer right after the
+        # tile kernel (obj/core.py:638); a row band of a multi-GPU split is rendered without it
         overlay = self.draw_debug_frustum and row_band is None
-        out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, keep_float=overlay,
-                             counters=False, keep_buffers=overlay, timing=False)
-        self.last_stats = backend.last_stats
+        out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, counters=False,
+                             keep_buffers=False, timing=False, overlay=overlay)
         if report:
             self._print_face_report(backend.read_face_status())
-        if overlay:
-            # debug aid (obj/core.py:638): drawn on the host into the device's float frame and
-            # z-buffer, then finalised with the reference's own expression (obj/core.py:640)
-            from .frustums import draw_view_frustum
-            frame, z_buffer = backend.read_frame_f32(), backend.read_z()
-            debug = self.debug_camera if self.debug_camera is not None else self.camera
-            draw_view_frustum(frame, self.camera, debug, z_buffer, self.system)
-            out = (frame[::-1] ** 0.8 * 255).astype(np.uint8)
         return out
 
     def _print_face_report(self, status):

@@ -31,6 +31,7 @@
 #include "rast_types.h"
 #include "kernels_geometry.h"
 #include "kernels_tile.h"
+#include "kernels_overlay.h"
 
 namespace {
 
@@ -142,6 +143,8 @@ struct mr_scene {
 
     // ---- device copies of the static scene
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edges, d_edge_inc, d_face_n;
+    DevBuf d_ov_seg_first, d_ov_seg_count, d_ov_target, d_ov_next, d_ov_z, d_ov_touched, d_ov_keep, d_ov_blend;
+    int32_t ov_segments = 0, ov_points = 0, ov_touched = 0, ov_max_target = -1;     // debug-frustum overlay statement lists
     DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
     DevBuf d_gamma;                          // GAMMA_LUT_SIZE float32 thresholds of the finalise step function
     int32_t sky_size = 0;
@@ -391,6 +394,14 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     hipStream_t stream = fs->stream;
     FrameConst fc = make_const(sc, fr);
     if (fc.flags & MR_FRAME_FACE_STATUS) fc.flags |= MR_FRAME_KEEP_BUFFERS;
+    const bool overlay = (fc.flags & MR_FRAME_OVERLAY) && sc->ov_points > 0;
+    if (fc.flags & MR_FRAME_OVERLAY) {
+        if (fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1)
+            return fail(MR_E_INVALID, "the debug-frustum overlay needs the whole frame on one device (no row band, no stripes)");
+        if ((long long)sc->ov_max_target >= (long long)fc.width * fc.height)
+            return fail(MR_E_INVALID, "overlay statement lists were built for a larger frame");
+        fc.flags |= MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT;
+    }
     const size_t npx = (size_t)fc.width * fc.height;
     const int n_tiles = fc.tiles_x * fc.tiles_y;
     const bool shadows = (fc.flags & MR_FRAME_SHADOWS) != 0;
@@ -540,6 +551,17 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
                            fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(), fs->d_clips.as<TriClip>(),
                            fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>());
+    if (overlay) {                          // after the lit pass' per-face verdicts, as in obj/core.py:624-638
+        OverlayArgs oa;
+        oa.seg_first = sc->d_ov_seg_first.as<int32_t>(); oa.seg_count = sc->d_ov_seg_count.as<int32_t>();
+        oa.target = sc->d_ov_target.as<int32_t>(); oa.next = sc->d_ov_next.as<int32_t>();
+        oa.z = sc->d_ov_z.as<double>(); oa.touched = sc->d_ov_touched.as<int32_t>();
+        oa.n_segments = sc->ov_segments; oa.n_points = sc->ov_points; oa.n_touched = sc->ov_touched;
+        oa.keep = sc->d_ov_keep.as<uint8_t>(); oa.blend = sc->d_ov_blend.as<float>();
+        oa.zbuf = fs->d_z.as<double>(); oa.frame = fs->d_frame.as<float>(); oa.out = d_out;
+        oa.gamma_lut = sc->d_gamma.as<float>();
+        hipLaunchKernelGGL(k_overlay, dim3(1), dim3(OVERLAY_BLOCK), 0, stream, fc, oa);
+    }
     HIP_TRY(hipGetLastError());
     fs->last_frame = *fr;
     fs->last_frame.flags = fc.flags;
@@ -553,12 +575,13 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
 
 // The fragment / pixel counts of a frame are left as per-tile partials by the tile kernel; they
 // are summed and fetched only when somebody asks (mr_render, mr_get_stats).
-int fetch_counters(mr_scene *sc, FrameSlot *fs)
+int fetch_counters(mr_scene *sc, FrameSlot *fs, bool reduce)
 {
     using namespace mr;
     (void)sc;
     Counters *ctr = fs->ctr(fs->frames_enqueued - 1);
-    if (!fs->stats_reduced && fs->last_n_tiles > 0) {
+    // mr_render without a stats pointer only needs the overflow flags: no reduction launch
+    if (reduce && !fs->stats_reduced && fs->last_n_tiles > 0) {
         hipLaunchKernelGGL(k_reduce_tile_stats, dim3(256), dim3(256), 0, fs->stream, fs->d_tile_stats.as<uint32_t>(),
                            fs->last_n_tiles, ctr);
         fs->stats_reduced = true;
@@ -639,6 +662,7 @@ int mr_abi_struct_size(int which)
     case 1: return (int)sizeof(mr_material);
     case 2: return (int)sizeof(mr_model_desc);
     case 3: return (int)sizeof(mr_stats);
+    case 4: return (int)sizeof(mr_overlay_desc);
     default: return -1;
     }
 }
@@ -702,7 +726,9 @@ void mr_scene_destroy(mr_scene *sc)
     if (!sc) return;
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
-                       &sc->d_textures, &sc->d_edges, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma };
+                       &sc->d_textures, &sc->d_edges, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma,
+                       &sc->d_ov_seg_first, &sc->d_ov_seg_count, &sc->d_ov_target, &sc->d_ov_next, &sc->d_ov_z,
+                       &sc->d_ov_touched, &sc->d_ov_keep, &sc->d_ov_blend };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();
     delete sc;
@@ -738,6 +764,57 @@ int mr_scene_set_skybox(mr_scene *sc, const uint8_t *texels, int32_t size)
     HIP_TRY(sc->d_sky.ensure(bytes));
     HIP_TRY(hipMemcpy(sc->d_sky.p, texels, bytes, hipMemcpyHostToDevice));
     sc->sky_size = size;
+    return MR_OK;
+}
+
+int mr_scene_set_overlay(mr_scene *sc, const mr_overlay_desc *ov)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());          // no frame may still be replaying the old lists
+    sc->ov_segments = sc->ov_points = sc->ov_touched = 0;
+    sc->ov_max_target = -1;
+    if (!ov || ov->n_points <= 0 || ov->n_segments <= 0) return MR_OK;
+    if (!ov->seg_first || !ov->seg_count || !ov->target || !ov->next || !ov->z || (ov->n_touched > 0 && !ov->touched))
+        return fail(MR_E_INVALID, "overlay description has NULL arrays");
+    const int np = ov->n_points;
+    // validate before the kernel trusts them: segments inside the point range, links inside their own
+    // segment and pointing forward (so every chain ends), targets non-negative
+    std::vector<int32_t> seg_of((size_t)np, -1);
+    for (int s = 0; s < ov->n_segments; ++s) {
+        const long long first = ov->seg_first[s], count = ov->seg_count[s];
+        if (first < 0 || count < 0 || first + count > np) return fail(MR_E_INVALID, "overlay segment outside the point array");
+        for (long long p = first; p < first + count; ++p) seg_of[(size_t)p] = s;
+    }
+    int32_t max_target = -1;
+    for (int k = 0; k < mr::OVERLAY_TARGETS; ++k)
+        for (int p = 0; p < np; ++p) {
+            const int32_t t = ov->target[(size_t)k * np + p], nx = ov->next[(size_t)k * np + p];
+            if (t < 0) return fail(MR_E_INVALID, "negative overlay target");
+            max_target = std::max(max_target, t);
+            if (nx != -1 && (nx <= p || nx >= np || seg_of[(size_t)nx] != seg_of[(size_t)p]))
+                return fail(MR_E_INVALID, "overlay link must point forward inside its own segment");
+        }
+    for (int i = 0; i < ov->n_touched; ++i) {
+        if (ov->touched[i] < 0) return fail(MR_E_INVALID, "negative overlay target");
+        max_target = std::max(max_target, ov->touched[i]);
+    }
+    auto up = [&](DevBuf &buf, const void *src, size_t bytes) -> int {
+        HIP_TRY(buf.ensure(std::max<size_t>(bytes, 16)));
+        if (bytes) HIP_TRY(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+        return MR_OK;
+    };
+    if ((rc = up(sc->d_ov_seg_first, ov->seg_first, (size_t)ov->n_segments * 4))) return rc;
+    if ((rc = up(sc->d_ov_seg_count, ov->seg_count, (size_t)ov->n_segments * 4))) return rc;
+    if ((rc = up(sc->d_ov_target, ov->target, (size_t)mr::OVERLAY_TARGETS * np * 4))) return rc;
+    if ((rc = up(sc->d_ov_next, ov->next, (size_t)mr::OVERLAY_TARGETS * np * 4))) return rc;
+    if ((rc = up(sc->d_ov_z, ov->z, (size_t)np * 8))) return rc;
+    if ((rc = up(sc->d_ov_touched, ov->touched, (size_t)std::max(ov->n_touched, 0) * 4))) return rc;
+    HIP_TRY(sc->d_ov_keep.ensure((size_t)np));
+    HIP_TRY(sc->d_ov_blend.ensure((size_t)np * 3 * sizeof(float)));
+    sc->ov_segments = ov->n_segments; sc->ov_points = np; sc->ov_touched = std::max(ov->n_touched, 0);
+    sc->ov_max_target = max_target;
     return MR_OK;
 }
 
@@ -827,7 +904,7 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     for (int attempt = 0; attempt < 6; ++attempt) {
         HIP_TRY(fs->d_out.ensure(band_bytes));
         if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
-        if ((rc = fetch_counters(sc, fs))) return rc;
+        if ((rc = fetch_counters(sc, fs, stats != nullptr))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
         if (!(fr->flags & MR_FRAME_NO_TIMING)) HIP_TRY(hipEventRecord(fs->ev[5], g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
@@ -839,6 +916,22 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
         if (rc != MR_E_OVERFLOW) return rc;       // work lists were grown: render the frame again
     }
     return fail(MR_E_OVERFLOW, "work lists kept overflowing");
+}
+
+void *mr_host_alloc(uint64_t bytes)
+{
+    if (ensure_init() != MR_OK) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) {
+        fail(MR_E_DEVICE, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void mr_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int mr_render_device(mr_scene *sc, const mr_frame_desc *fr, void *d_out_rgb, void *stream)
@@ -862,7 +955,7 @@ int mr_get_stats(mr_scene *sc, mr_stats *stats)
     bool overflowed = false;
     for (auto &s : sc->slots) {
         if (!s->have_frame) continue;
-        int rc = fetch_counters(sc, s.get());
+        int rc = fetch_counters(sc, s.get(), true);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));
         if (collect(sc, s.get(), false) == MR_E_OVERFLOW) overflowed = true;

@@ -1,12 +1,15 @@
-"""Debug-camera frustum overlay (host side).
+"""Debug-camera frustum overlay.
 
 The reference ends every ``render()`` by drawing the *debug camera's* view frustum as red,
 z-tested lines into the float frame and the z-buffer (``obj/core.py:638``,
-``obj/frustums.py:46-103``, ``obj/line.py:6-16``).  It is a debugging aid whose result depends
-on the order of its own writes (each line segment is tested against z values earlier segments
-left behind), a few thousand pixels in all, so it is applied on the host to the buffers the
-device produced: ``Scene.render`` downloads the float frame and z-buffer only when
-``scene.draw_debug_frustum`` is set (off by default; the reference cannot switch it off).
+``obj/frustums.py:46-103``, ``obj/line.py:6-16``).  The geometry -- clipping the frustum's six
+faces, projecting them, walking their edges with a DDA, dashing the hidden ones -- is a few
+thousand points of sequential float64 arithmetic and stays on the host (``overlay_segments``).
+What the lines DO to the frame depends on the frame's own z-buffer and on the order of their
+writes (each segment is tested against the z values earlier segments left behind), so that part
+runs where the z-buffer is: ``OverlayOps`` flattens the segments into the statement lists the
+device replays (``k_overlay`` in ``csrc/kernels_overlay.h``) right after the tile kernel, and
+``draw_view_frustum`` replays the same lists on NumPy buffers (the CPU tests use it on the oracle's).
 """
 import numpy as np
 
@@ -34,16 +37,17 @@ def bresenham_line(start_point, end_point):
     return start_point + np.arange(int(steps))[:, None] * (delta / steps)
 
 
-def draw_view_frustum(frame, camera, positioned_object, z_buffer, sign):
-    """Draw *positioned_object*'s frustum as seen by *camera* into ``frame`` / ``z_buffer`` in place."""
+def overlay_segments(camera, positioned_object):
+    """The line segments of *positioned_object*'s frustum as seen by *camera*, in drawing order: a
+    list of ``(row, col, z)`` arrays (int32, int32, float64; row = screen y, not flipped), one per
+    polygon edge (``obj/frustums.py:46-91``)."""
     corners = CUBE @ np.linalg.inv(positioned_object.MVP)
     corners /= corners[W_COL]
     planes = camera.frustum_planes
     probe = np.append(camera.position, 1) @ positioned_object.MVP
     camera_inside = all(-probe[3] < probe[k] < probe[3] for k in range(3))
     near_far = 2 * camera.near * camera.far
-    last_row, last_col = np.array(camera.scene.resolution) - 1
-
+    segments = []
     for quad in corners[CUBE_FACES]:
         poly = clipping(quad, planes)
         if poly.shape[0] < 3:
@@ -60,16 +64,91 @@ def draw_view_frustum(frame, camera, positioned_object, z_buffer, sign):
             if facing > 0 and not camera_inside:                      # hidden edge: dashed
                 pts = pts[((np.arange(len(pts)) // DASH) & 1).astype(bool)]
             col, row, z, _ = pts.T
-            row = row.astype(np.int32) - 1
-            col = col.astype(np.int32) - 1
-            keep = (z_buffer[row, col] - z) * sign >= 0
-            row, col, z = row[keep], col[keep], z[keep]
-            z_buffer[row, col] = z
-            frame[row, col] = RED
-            for step in (-1, 1):                                      # one-pixel soft edge
-                r2 = np.clip(row + step, a_min=0, a_max=last_row)
-                c2 = np.clip(col + step, a_min=0, a_max=last_col)
-                z_buffer[r2, col] = z
-                z_buffer[row, c2] = z
-                frame[r2, col] = frame[r2, col] * 0.5 + RED / 2
-                frame[row, c2] = frame[row, c2] * 0.5 + RED / 2
+            segments.append((row.astype(np.int32) - 1, col.astype(np.int32) - 1, np.ascontiguousarray(z, dtype=np.float64)))
+    return segments
+
+
+class OverlayOps:
+    """The overlay as flat statement lists (what ``mr_scene_set_overlay`` takes).
+
+    Every kept point of a segment performs, in this order (``obj/frustums.py:93-103``): the centre write
+    (z and RED), then for step -1 and +1: z into the row neighbour, z into the column neighbour, a
+    half blend into the row neighbour, a half blend into the column neighbour -- each a NumPy fancy
+    assignment over all kept points of the segment, i.e. the right-hand side is read before anything
+    is written and, where several points hit one pixel, the last one wins.  Five target sets per
+    point (centre, row-1, col-1, row+1, col+1 with the neighbours clipped to the frame), and per
+    target set the link to the next point of the same segment with the same target, which is what
+    "the last one wins" needs on a machine that writes them all at once."""
+
+    N_TARGETS = 5
+
+    def __init__(self, camera, positioned_object, resolution):
+        height, width = (int(v) for v in resolution)
+        self.height, self.width = height, width
+        seg_first, seg_count, target, nxt, zs = [], [], [[] for _ in range(5)], [[] for _ in range(5)], []
+        base = 0
+        for row, col, z in overlay_segments(camera, positioned_object):
+            n = len(z)
+            if n == 0:
+                continue
+            # Python / NumPy index semantics: a negative index counts from the end; anything else out of
+            # range raises IndexError in the reference (there the frame is lost; here the point is)
+            ok = (row >= -height) & (row < height) & (col >= -width) & (col < width)
+            row, col, z = row[ok], col[ok], z[ok]
+            n = len(z)
+            if n == 0:
+                continue
+            wrow, wcol = row % height, col % width                     # the centre index wraps like Python's
+            # the neighbours are clipped from the RAW index (np.clip(x + i, 0, last)), so a point at -1
+            # wraps to the last row but its neighbours are row 0 (obj/frustums.py:97-103)
+            sets = ((wrow, wcol), (np.clip(row - 1, 0, height - 1), wcol), (wrow, np.clip(col - 1, 0, width - 1)),
+                    (np.clip(row + 1, 0, height - 1), wcol), (wrow, np.clip(col + 1, 0, width - 1)))
+            for k, (r, c) in enumerate(sets):
+                lin = (r.astype(np.int64) * width + c).astype(np.int32)
+                link = np.full(n, -1, np.int32)
+                last = {}
+                for i in range(n - 1, -1, -1):           # next point (later in the segment) with the same target
+                    link[i] = last.get(int(lin[i]), -1)
+                    last[int(lin[i])] = base + i
+                target[k].append(lin)
+                nxt[k].append(link)
+            zs.append(z)
+            seg_first.append(base)
+            seg_count.append(n)
+            base += n
+        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(0, dt), dtype=dt)
+        self.seg_first = np.asarray(seg_first, np.int32)
+        self.seg_count = np.asarray(seg_count, np.int32)
+        self.target = np.ascontiguousarray(np.stack([cat(t, np.int32) for t in target]))      # (5, n_points)
+        self.next = np.ascontiguousarray(np.stack([cat(t, np.int32) for t in nxt]))
+        self.z = cat(zs, np.float64)
+        self.touched = np.unique(self.target).astype(np.int32) if self.z.size else np.zeros(0, np.int32)
+
+    @property
+    def n_points(self):
+        return int(self.z.size)
+
+    def replay(self, frame, z_buffer, sign):
+        """Apply the statements to NumPy buffers in place (float32 (H, W, 3) frame, float64 (H, W) z)."""
+        zf, ff = z_buffer.reshape(-1), frame.reshape(-1, 3)
+        half_red = RED / 2
+        for first, count in zip(self.seg_first, self.seg_count):
+            sl = slice(first, first + count)
+            z = self.z[sl]
+            keep = (zf[self.target[0, sl]] - z) * sign >= 0
+            zk = z[keep]
+            centre = self.target[0, sl][keep]
+            zf[centre] = zk
+            ff[centre] = RED
+            for step in (0, 2):                                       # row / col neighbours at -1, then at +1
+                rn, cn = self.target[1 + step, sl][keep], self.target[2 + step, sl][keep]
+                zf[rn] = zk
+                zf[cn] = zk
+                ff[rn] = ff[rn] * 0.5 + half_red
+                ff[cn] = ff[cn] * 0.5 + half_red
+
+
+def draw_view_frustum(frame, camera, positioned_object, z_buffer, sign):
+    """Draw *positioned_object*'s frustum as seen by *camera* into ``frame`` / ``z_buffer`` in place
+    (host replay of the statement lists; ``obj/frustums.py:46-103``)."""
+    OverlayOps(camera, positioned_object, z_buffer.shape).replay(frame, z_buffer, sign)

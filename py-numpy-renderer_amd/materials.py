@@ -22,9 +22,15 @@ _DEFAULTS = dict(
 
 
 class Material:
-    """Attribute bag; texture maps are float32 (H, W, 3) arrays under ``map_*`` / ``norm``."""
+    """Attribute bag; texture maps are float32 (H, W, 3) arrays under ``map_*`` / ``norm``.
+
+    Every assignment bumps ``Material.revision`` (class-wide): the device copy of a scene is refreshed
+    when it changed since the last frame, so ``material.Kd = [...]`` between two renders is picked up."""
+
+    revision = 0
 
     def __setattr__(self, key, value):
+        Material.revision += 1
         if len(value) == 1:
             item = value[0]
             try:

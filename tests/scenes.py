@@ -183,6 +183,11 @@ def _scene(api, cam, dbg, light, resolution, models, **kw):
     sc = api.Scene(cam, light, debug_camera=dbg, resolution=resolution, **kw)
     for m in models:
         sc.add_model(m)
+    # The captures under tests/golden/ were taken with the reference's debug-frustum overlay patched out
+    # (make_golden.py), the *_overlay ones with it left on; the product's switch for it defaults to ON like
+    # upstream, so the recipes turn it off and the overlay tests turn it back on.  (On the reference's
+    # Scene this is just an unused attribute.)
+    sc.draw_debug_frustum = False
     return sc
 
 

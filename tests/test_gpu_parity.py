@@ -309,6 +309,27 @@ def test_scene_changes_are_picked_up(api, oracle_mod):
     sc.close()
 
 
+def test_in_place_edits_are_picked_up(api, oracle_mod):
+    """Editing a model's arrays in place, or a material's fields the way parse_mtl assigns them, between
+    two renders re-uploads the scene (the change detector fingerprints content, not object identity)."""
+    cam, dbg = scenes._std_cameras(api)
+    tet = api.Model.load_model(scenes.bare_tetra_obj())
+    sc = scenes._scene(api, cam, dbg, scenes._std_light(api), (90, 120), [tet, scenes._floor(api, textured=False)])
+    first = sc.render()
+    tet.vertices[:, :3] *= np.float32(0.7)                      # in place: same array object
+    second = sc.render()
+    assert not np.array_equal(first, second)
+    _against_oracle(api, oracle_mod, sc, label="after in-place vertex edit")
+    tet.materials["default"].Kd = ["0.9", "0.2", "0.1"]           # the way parse_mtl assigns (obj/core.py:346)
+    third = sc.render()
+    assert not np.array_equal(second, third)
+    _against_oracle(api, oracle_mod, sc, label="after material edit")
+    tet.vertices[0, 1] += np.float32(0.2)                       # a single element: needs invalidate()
+    tet.invalidate()
+    _against_oracle(api, oracle_mod, sc, label="after invalidate()")
+    sc.close()
+
+
 @pytest.mark.parametrize("in_flight", [1, 4])
 def test_frames_in_flight_all_match(api, in_flight):
     """bench.py's mode: successive frames enqueued on several HIP streams (mr_render_device), each
