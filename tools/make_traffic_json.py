@@ -1,15 +1,20 @@
-"""gpurun_out/pmc/traffic/traffic_raw.json (tools/prof_traffic.sh) -> profiles/<round>_traffic.json:
-HBM bytes per launch of the three tile kernels, as bench.py's roofline.traffic reads them."""
+"""gpurun_out/pmc/traffic_<tag>/traffic_raw.json (tools/prof_traffic.sh) -> profiles/<round>_traffic.json:
+HBM bytes per launch of the frame's kernels, per config, as bench.py's roofline.traffic reads them.
+    python tools/make_traffic_json.py r02 c4 c5"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-raw = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc", "traffic", "traffic_raw.json")))
-out = {}
-for kernel, key in (("k_shade", "shade"), ("k_tile_raster", "tile_raster"), ("k_tile_quads", "tile_quads")):
-    out[key] = int((2 * raw[kernel]["fetch"] + raw[kernel]["write"]) * 1024)
-out["_note"] = ("HBM bytes per launch on BASELINE config c4 (1920x1080, 200k tris), frame-only mode as bench.py renders: "
-                "(2*FETCH_SIZE + WRITE_SIZE)*1024 from two separate rocprofv3 --pmc passes (tools/prof_traffic.sh); "
-                "the factor 2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (checked on k_vertex: "
-                "3.2 MB read -> FETCH_SIZE ~1585 KB)")
-out["_raw_kb"] = raw
-json.dump(out, open(os.path.join(ROOT, "profiles", sys.argv[1] + "_traffic.json"), "w"), indent=1)
-print({k: v for k, v in out.items() if not k.startswith("_")})
+rnd, tags = sys.argv[1], sys.argv[2:]
+path = os.path.join(ROOT, "profiles", rnd + "_traffic.json")
+out = json.load(open(path)) if os.path.exists(path) else {}
+for tag in tags:
+    raw = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc", f"traffic_{tag}", "traffic_raw.json")))
+    out[tag] = {k: int((2 * v.get("fetch", 0) + v.get("write", 0)) * 1024) for k, v in raw.items() if k.startswith("k_")}
+    out[tag]["_raw_kb"] = {k: {m: round(x, 2) for m, x in v.items()} for k, v in raw.items() if k.startswith("k_")}
+out["_note"] = ("HBM bytes per launch, frame-only mode as bench.py renders (tools/render_loop.py, steady state): "
+                "(2*FETCH_SIZE + WRITE_SIZE)*1024 from two separate rocprofv3 --pmc passes (tools/prof_traffic.sh). "
+                "FETCH_SIZE on gfx950 counts every 128-byte line fetched as 64 bytes, whatever the access shape "
+                "(tools/micro/fetch_calib.hip, profiles/r02_fetch_calibration.json: streaming, 12-byte texel gathers, "
+                "112/176/192-byte record gathers all read FETCH_SIZE = lines x 64 B), hence the factor 2: the figure is "
+                "whole lines moved, not payload bytes")
+json.dump(out, open(path, "w"), indent=1)
+print({t: {k: v for k, v in out[t].items() if not k.startswith("_")} for t in tags})
