@@ -131,7 +131,8 @@ typedef struct mr_model_desc {
     int32_t vertices_are_f32;       /* Model.vertices.dtype == float32: edge vectors and the silhouette
                                        normal are then formed in float32 like NumPy does */
     int32_t clip;                   /* Model.clip */
-    int32_t depth_test;             /* Model.depth_test (0 is MR_E_UNSUPPORTED) */
+    int32_t depth_test;             /* Model.depth_test; 0: the model's fragments are tested against the z-buffer but
+                                       never written to it (obj/triangular.py:117) */
 } mr_model_desc;
 
 /* Counters of the last mr_render call (BASELINE.md fragment definition). */

@@ -531,10 +531,8 @@ static int rasterize(const ctx_t *c, const orc_texture *textures, const orc_mode
     const int single_shade = keep == 1;
     for (size_t i = 0; i < keep; ++i) {
         size_t at = (size_t)fr[i].py * W + fr[i].px;
-        if (!second_pass && m->depth_test) {
-            o->z[at] = fr[i].z;
-            if (o->winner) o->winner[at] = gid;
-        }
+        if (!second_pass && m->depth_test) o->z[at] = fr[i].z;
+        if (!second_pass && o->winner) o->winner[at] = gid;      /* who wrote the pixel last in pass 1, z-writing or not */
         if (o->frame) shade(c, textures, &t, fr[i].b, single_shade, !second_pass, o->frame + at * 3);
     }
     return 0;

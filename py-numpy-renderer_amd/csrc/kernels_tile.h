@@ -56,6 +56,9 @@ __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t
     const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
     const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
     const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    // Model.depth_test == False (obj/triangular.py:117): the face's fragments are tested, never written to z.
+    // The pixel then shows the LAST face in order among those that pass against the final z (see k_tile).
+    const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
     const int bw = x1 - x0;
     if (bw <= 0) return;
     int px = x0 + sub, py = y0;
@@ -65,7 +68,7 @@ __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t
         tri_bary(t, (double)px, (double)py, single, u, v, w);
         bool ok = u >= 0 && v >= 0 && w >= 0;
         if (ok && SWEEP == 0) ++frags;
-        if (ok) {
+        if (ok && (SWEEP == 1 || !nodepth)) {
             const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
                                        t.zl0, t.zl1, t.zl2);
             if (z == z) {                            // a NaN depth never passes the reference's test
@@ -73,7 +76,7 @@ __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t
                 const unsigned long long k = z_key(z);
                 if (SWEEP == 0) {
                     if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
-                } else if (s_key[p] == k) {
+                } else if (nodepth ? (rh ? k <= s_key[p] : k >= s_key[p]) : s_key[p] == k) {
                     atomicMax(&s_win[p], t.face);
                 }
             }
@@ -242,41 +245,54 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     // wavefront on top of the arithmetic; scalar loads cost a dependent memory round trip per pair.
     constexpr int TRI_U4 = (int)(sizeof(TriRec) / 16);
     static_assert(WAVE * TRI_U4 <= QUAD_BATCH * QUAD_STAGE_U4, "big-pair records are staged in the quad area");
-    for (uint32_t base = 0; base < n_big; base += WAVE) {
-        const int n = (int)min((uint32_t)WAVE, n_big - base);
-        if (base) __syncthreads();                        // the previous chunk has been read
-        for (int i = tid; i < n * TRI_U4; i += TILE_PX) {
-            const int q = i / TRI_U4, piece = i - q * TRI_U4;
-            s_quad[i] = reinterpret_cast<const uint4 *>(tris + big_items[base + q])[piece];
-        }
-        __syncthreads();
-        for (int j = 0; j < n; ++j) {
-            const TriRec &t = *reinterpret_cast<const TriRec *>(s_quad + j * TRI_U4);
-            const uint32_t flags = t.flags;
-            const int f = t.face;
-            const bool single = (flags & TF_SINGLE_BOX) != 0;
-            bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
-            float u, v, w;
-            tri_bary(t, dpx, dpy, single, u, v, w);
-            in = in && u >= 0 && v >= 0 && w >= 0;
-            const unsigned long long m = __ballot(in);
-            if (!m) continue;
-            frags += (unsigned int)__popcll(m);
-            if (flags & TF_CLIP) {
-                if (in) {
-                    const TriClip &c = ta.clips[f];
-                    const TriAttr &at = sh.attrs[f];
-                    double p[3];
-                    persp_bary(at.dp, u, v, w, single, p);
-                    in = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
+    // LATE == false: the faces that write z.  LATE == true (only in scenes that have a model with
+    // depth_test == False, after the tile's final z is known): those that do not -- they own the pixel
+    // when they pass against the final z and come later in face order than the current owner.
+    auto big_pairs = [&](const bool late) {
+        for (uint32_t base = 0; base < n_big; base += WAVE) {
+            const int n = (int)min((uint32_t)WAVE, n_big - base);
+            if (base || late) __syncthreads();            // the staging area is free
+            for (int i = tid; i < n * TRI_U4; i += TILE_PX) {
+                const int q = i / TRI_U4, piece = i - q * TRI_U4;
+                s_quad[i] = reinterpret_cast<const uint4 *>(tris + big_items[base + q])[piece];
+            }
+            __syncthreads();
+            for (int j = 0; j < n; ++j) {
+                const TriRec &t = *reinterpret_cast<const TriRec *>(s_quad + j * TRI_U4);
+                const uint32_t flags = t.flags;
+                const bool nodepth = ((flags >> 8) & FF_NO_DEPTH) != 0;
+                if (late && !nodepth) continue;
+                const int f = t.face;
+                const bool single = (flags & TF_SINGLE_BOX) != 0;
+                bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
+                float u, v, w;
+                tri_bary(t, dpx, dpy, single, u, v, w);
+                in = in && u >= 0 && v >= 0 && w >= 0;
+                const unsigned long long m = __ballot(in);
+                if (!m) continue;
+                if (!late) frags += (unsigned int)__popcll(m);
+                if (nodepth && !late) continue;
+                if (flags & TF_CLIP) {
+                    if (in) {
+                        const TriClip &c = ta.clips[f];
+                        const TriAttr &at = sh.attrs[f];
+                        double p[3];
+                        persp_bary(at.dp, u, v, w, single, p);
+                        in = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
+                    }
+                }
+                const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
+                if (late) {
+                    if (in && (rh ? z <= zbest : z >= zbest) && f > best) best = f;
+                } else {
+                    // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
+                    const bool closer = rh ? (z < zbest) : (z > zbest);
+                    if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
                 }
             }
-            const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
-            // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
-            const bool closer = rh ? (z < zbest) : (z > zbest);
-            if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
         }
-    }
+    };
+    big_pairs(false);
     __syncthreads();                                      // s_cnt is zeroed, the LDS tables are loaded
     if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
     if (n_small) {
@@ -304,6 +320,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         best = s_win[lp];
         zbest = z_unkey(kfinal);
     }
+    if (fc.has_no_depth) big_pairs(true);
     const bool covered = live && best >= 0;
     const unsigned long long t_raster = __builtin_amdgcn_s_memrealtime();
 

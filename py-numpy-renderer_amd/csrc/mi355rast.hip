@@ -366,6 +366,8 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
     std::memcpy(fc.sky_tri, fr->sky_tri, sizeof fc.sky_tri);
     std::memcpy(fc.sky_rays, fr->sky_rays, sizeof fc.sky_rays);
     fc.sky_size = sc->sky_size;
+    fc.has_no_depth = 0;
+    for (uint8_t ff : sc->face_flags) if (ff & mr::FF_NO_DEPTH) { fc.has_no_depth = 1; break; }
     fc.same_clip = memcmp(fr->mvp, fr->debug_mvp, sizeof(fr->mvp)) == 0 ? 1 : 0;
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
@@ -823,8 +825,6 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
     if (!sc || !m) return fail(MR_E_INVALID, "NULL argument");
     if (!m->vertices || !m->faces || !m->materials || m->n_vertices <= 0 || m->n_faces < 0 || m->n_materials <= 0)
         return fail(MR_E_INVALID, "model needs vertices, faces and at least one material");
-    if (!m->depth_test)
-        return fail(MR_E_UNSUPPORTED, "Model.depth_test=False makes the result depend on face order; not implemented");
     const int n_tex = (int)sc->textures.size();
     for (int i = 0; i < m->n_materials; ++i) {
         const mr_material &mm = m->materials[i];
@@ -864,7 +864,8 @@ int mr_scene_add_model(mr_scene *sc, const mr_model_desc *m)
         sc->materials.push_back(d);
     }
     const uint8_t ff = (uint8_t)((m->clip ? mr::FF_CLIP : 0) | (m->vertices_are_f32 ? mr::FF_VERTS_F32 : 0) |
-                                 (m->normals ? mr::FF_HAS_NORMALS : 0) | (m->uv ? mr::FF_HAS_UV : 0));
+                                 (m->normals ? mr::FF_HAS_NORMALS : 0) | (m->uv ? mr::FF_HAS_UV : 0) |
+                                 (m->depth_test ? 0 : mr::FF_NO_DEPTH));
     sc->faces.reserve(sc->faces.size() + (size_t)m->n_faces * 12);
     for (int64_t i = 0; i < (int64_t)m->n_faces * 3; ++i) {
         const int32_t *c = m->faces + i * 4;

@@ -28,7 +28,8 @@ enum : uint8_t {
 };
 
 // per-face flags copied from the owning Model
-enum : uint8_t { FF_CLIP = 1, FF_VERTS_F32 = 2, FF_HAS_NORMALS = 4, FF_HAS_UV = 8 };
+enum : uint8_t { FF_CLIP = 1, FF_VERTS_F32 = 2, FF_HAS_NORMALS = 4, FF_HAS_UV = 8,
+                 FF_NO_DEPTH = 16 };    // Model.depth_test == False: tested against z, never written to it
 
 // TriRec.flags (bits 8-15 carry the face flags above)
 enum : uint32_t {
@@ -61,7 +62,7 @@ struct FrameConst {
     uint32_t background_u8;      // finalised background r | g << 8 | b << 16 | 1 << 24 (0 = not given)
     int32_t sky_tri[12];         // skybox triangles' integer screen vertices [t][v][xy]
     int32_t sky_size;            // cubemap face size
-    int32_t pad0;
+    int32_t has_no_depth;        // some model has depth_test == False (the tile kernel then runs its second look at the big pairs)
     double sky_rays[18];         // their un-projected corner rays [t][v][xyz]
 };
 

@@ -318,6 +318,20 @@ def kat_house(api, resolution=(150, 200)):
     return _scene(api, cam, dbg, _std_light(api, specular_strength=0.4), resolution, [house, porch, _floor(api)])
 
 
+def cube_tetra_nodepth(api, resolution=(120, 160)):
+    """``Model.depth_test = False`` (obj/core.py:235-241, obj/triangular.py:117): a tetrahedron that is tested
+    against the z-buffer but never writes to it, between two z-writing models in model order, poking
+    through the cube (so it wins some pixels, loses others, and later faces draw over it)."""
+    cam, dbg = _std_cameras(api)
+    cube = api.Model.load_model(os.path.join(ASSETS, "cube", "cube.obj"))
+    cube.normals = -cube.normals
+    cube = cube @ api.scale(0.45)
+    tet = api.Model.load_model(bare_tetra_obj())
+    tet.depth_test = False
+    tet = tet @ api.scale(1.3)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [cube, tet, _floor(api)])
+
+
 def tetra_ortho(api, resolution=(120, 160)):
     """Orthographic camera (obj/transformation.py:139-154; only OpenGL + LH exists upstream):
     near = |position| (obj/core.py:389), float32 projection matrix."""
@@ -345,6 +359,7 @@ SMALL = {
     "diablo_closeup_noclip": (diablo_closeup_noclip, {}),
     "kat_house": (kat_house, {}),
     "tetra_ortho": (tetra_ortho, {}),
+    "cube_tetra_nodepth": (cube_tetra_nodepth, {}),
 }
 
 # BASELINE.json configs at full size: only the uint8 frame, winner map, stencil and z row sums are kept

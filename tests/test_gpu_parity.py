@@ -168,9 +168,14 @@ def test_errors_are_loud(api):
     lib = _native.load_library()
     assert lib.mr_device_available() == 1
     scene = scenes.build(api, "cube_small")
-    scene.models[0].depth_test = False
-    with pytest.raises(RuntimeError, match="depth_test"):
+    scene.models[0]._faces = scene.models[0]._faces[:, :, :3]          # corners without a material column
+    with pytest.raises(ValueError, match="_faces"):
         scene.render()
+    scene.close()
+    scene = scenes.build(api, "cube_small")
+    backend = scene._backend()
+    with pytest.raises(RuntimeError, match="whole frame"):
+        backend.render(scene, row_band=(0, 60), overlay=True)
     scene.close()
 
 
