@@ -297,8 +297,13 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
         status[f] = FACE_EMPTY_Z;
         return 0;
     }
-    // a device that renders a band of rows drops the faces whose pixel box misses the band right here
-    if (by1 <= fc.band_y0 || by0 >= fc.band_y1) { status[f] = FACE_CLIPPED; return 0; }
+    // a device that renders a band of rows, or interleaved tile rows, drops the faces whose pixel box touches
+    // none of its tiles right here, before any record is written (with N devices a dense mesh's set-up
+    // records are then written once across the node, not N times)
+    {
+        TileSpan own;
+        if (bx0 < bx1 && by0 < by1 && !tile_span(fc, bx0, bx1, by0, by1, own)) { status[f] = FACE_CLIPPED; return 0; }
+    }
     t.x0 = (int16_t)bx0; t.x1 = (int16_t)bx1; t.y0 = (int16_t)by0; t.y1 = (int16_t)by1;
     pb = { bx0, bx1, by0, by1 };
     t.ax = A.sx; t.ay = A.sy;

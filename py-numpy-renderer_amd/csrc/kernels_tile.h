@@ -155,7 +155,7 @@ struct TileArgs {
 // row-major order, i.e. round-robin over the XCDs: heavy tiles cluster on the screen, and an
 // XCD-contiguous mapping (tried first) left six of the eight XCDs idle behind the two that
 // owned the mesh and its shadow.
-__global__ void __launch_bounds__(TILE_PX)
+__global__ void __launch_bounds__(TILE_PX, 5)
 k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
 {
     __shared__ unsigned long long s_key[TILE_PX];
