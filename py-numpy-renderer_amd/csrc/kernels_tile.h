@@ -123,7 +123,19 @@ static_assert(sizeof(Material) % 8 == 0 && MAT_LDS * sizeof(Material) / 8 <= TIL
 // history (scene or camera changed) costs time, never correctness; a new tile grid starts with an
 // empty history.  (A loop "list entry, then own tile" inside one workgroup doubled the kernel's
 // register budget: the compiler hoists the frame constants' register copies out of the loop.)
-constexpr int HEAVY_CLASSES = 3, HEAVY_MAX = 512, HEAVY_FRONT = HEAVY_CLASSES * HEAVY_MAX;
+constexpr int HEAVY_CLASSES = 3, HEAVY_MAX = 512;
+// On a device that owns few tiles (a rank of a multi-GPU split: all its tiles are resident at once and
+// the launch lasts as long as its slowest tile) the heaviest class is not only started first: those
+// tiles' shadow quads -- walked one after the other, 0.4 us each, up to a hundred and more where a mesh's
+// outline and its shadow volume overlap -- are SHARED OUT over HEAVY_SPLIT workgroups.  Each of them
+// rasterises the tile (same lists, same order-free arithmetic: the same z and winners), counts its share
+// of the quads, and leaves its stencil counts in a scratch slot; the workgroup that arrives last (a
+// counter, no waiting) adds the others' and shades.  Only frames rendered for the frame's sake are split
+// (no MR_FRAME_COUNTERS), and only in the k_tile<true> instantiation: on a device that owns the whole
+// frame the launch is bound by the tiles' total work, which the repeated rasterisation only adds to
+// (measured on MI355X, c4: 86 -> 90 us whole frame; a rank of 8: 56 -> 38 us).
+constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = 128;
+constexpr int HEAVY_FRONT = HEAVY_SPLIT * HEAVY0_MAX + (HEAVY_CLASSES - 1) * HEAVY_MAX;
 struct TileHistory {
     uint32_t count[HEAVY_CLASSES + 1];
     uint32_t tiles[HEAVY_CLASSES][HEAVY_MAX];
@@ -145,6 +157,8 @@ struct TileArgs {
     int32_t *winner, *stencil;
     uint32_t *tile_stats;
     Counters *ctr, *next_ctr;     // this frame's counters; the next frame's (cleared here)
+    int32_t *split_sten;          // [HEAVY0_MAX][HEAVY_SPLIT][TILE_PX] stencil counts of a split tile's parts
+    uint32_t *split_arrive;       // [HEAVY0_MAX] parts that have left theirs (zero between frames)
     const TileHistory *hist;      // what the slot's previous frame learnt about its tiles
     TileHistory *next_hist;       // what this frame leaves for the next
     const uint8_t *heavy_flag;    // [n_tiles] != 0: the tile is in hist's lists
@@ -155,6 +169,7 @@ struct TileArgs {
 // row-major order, i.e. round-robin over the XCDs: heavy tiles cluster on the screen, and an
 // XCD-contiguous mapping (tried first) left six of the eight XCDs idle behind the two that
 // owned the mesh and its shadow.
+template <bool SPLIT>      // SPLIT: the heaviest tiles' shadow quads are shared out over HEAVY_SPLIT workgroups (see HEAVY_SPLIT)
 __global__ void __launch_bounds__(TILE_PX, 5)
 k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
 {
@@ -176,13 +191,19 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     if (blockIdx.x == (uint32_t)HEAVY_FRONT && tid == 0) *ta.next_ctr = Counters{};  // nobody touches the next frame's counters before this kernel ends
 
     // heavy tiles first (see TileHistory): entry blockIdx.x of the previous frame's lists, then the own tile
-    const uint32_t h0 = min(ta.hist->count[0], (uint32_t)HEAVY_MAX), h1 = h0 + min(ta.hist->count[1], (uint32_t)HEAVY_MAX),
-                   h2 = h1 + min(ta.hist->count[2], (uint32_t)HEAVY_MAX);
-    int tile;
-    if (blockIdx.x < (uint32_t)HEAVY_FRONT) {
-        const uint32_t b = blockIdx.x;
-        if (b >= h2) return;
-        tile = (int)(b < h0 ? ta.hist->tiles[0][b] : b < h1 ? ta.hist->tiles[1][b - h0] : ta.hist->tiles[2][b - h1]);
+    const uint32_t h0 = min(ta.hist->count[0], (uint32_t)HEAVY0_MAX), n1 = min(ta.hist->count[1], (uint32_t)HEAVY_MAX),
+                   n2 = min(ta.hist->count[2], (uint32_t)HEAVY_MAX);
+    int tile, part = 0, n_parts = 1, entry = 0;
+    if (blockIdx.x < (uint32_t)(HEAVY_SPLIT * HEAVY0_MAX)) {
+        entry = (int)blockIdx.x / HEAVY_SPLIT;
+        part = (int)blockIdx.x % HEAVY_SPLIT;
+        n_parts = (SPLIT && !counters) ? HEAVY_SPLIT : 1;
+        if (entry >= (int)h0 || part >= n_parts) return;
+        tile = (int)ta.hist->tiles[0][entry];
+    } else if (blockIdx.x < (uint32_t)HEAVY_FRONT) {
+        const uint32_t b = blockIdx.x - (uint32_t)(HEAVY_SPLIT * HEAVY0_MAX);
+        if (b >= n1 + n2) return;
+        tile = (int)(b < n1 ? ta.hist->tiles[1][b] : ta.hist->tiles[2][b - n1]);
     } else {
         tile = (int)blockIdx.x - HEAVY_FRONT;
         if (ta.heavy_flag[tile]) return;
@@ -342,9 +363,11 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
             zlim = rh ? fmax(zlim, o) : fmin(zlim, o);
             zhard = rh ? fmin(zhard, h) : fmax(zhard, h);
         }
-        for (uint32_t qbase = 0; qbase < n_quad; qbase += QUAD_BATCH) {
-            const int n = (int)min((uint32_t)QUAD_BATCH, n_quad - qbase);
-            if (qbase) __syncthreads();                   // the previous batch has been read
+        const uint32_t q_begin = SPLIT ? (uint32_t)((unsigned long long)part * n_quad / n_parts) : 0u,
+                       q_end = SPLIT ? (uint32_t)((unsigned long long)(part + 1) * n_quad / n_parts) : n_quad;    // this part's share
+        for (uint32_t qbase = q_begin; qbase < q_end; qbase += QUAD_BATCH) {
+            const int n = (int)min((uint32_t)QUAD_BATCH, q_end - qbase);
+            if (qbase != q_begin) __syncthreads();        // the previous batch has been read
             // Staging also folds two per-quad facts into the copy: a back-facing quad's edge vectors are
             // negated (the rounded cross product changes sign exactly, so "inner side" is "> 0" for every
             // staged quad), and the last 16 bytes of the header, unused here, receive f_plus_n * nz and
@@ -509,6 +532,31 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         }
     }
 
+    if (SPLIT && n_parts > 1) {
+        // Leave this part's counts, then take a ticket.  Hand-off between workgroups on different CUs
+        // (MI355X_MICROARCH.md, inter-workgroup visibility): plain stores, every wave's stores drained
+        // (the barrier waits for vmcnt(0)), ONE agent-scope release, then the relaxed ticket; the last
+        // arriver does ONE agent-scope acquire (invalidates its CU's L1) behind a barrier, then plain loads.
+        __shared__ uint32_t s_ticket;
+        int32_t *mine = ta.split_sten + ((size_t)entry * HEAVY_SPLIT + part) * TILE_PX;
+        mine[lp] = sten;
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_ticket = atomicAdd(&ta.split_arrive[entry], 1u);
+        }
+        __syncthreads();
+        if (s_ticket != (uint32_t)(n_parts - 1)) return;  // not the last one: whoever is adds these counts and shades
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ta.split_arrive[entry] = 0;                   // every part has arrived: ready for the next frame
+        }
+        __syncthreads();
+        for (int k = 0; k < n_parts; ++k)
+            if (k != part) sten += ta.split_sten[((size_t)entry * HEAVY_SPLIT + k) * TILE_PX + lp];
+    }
     const unsigned long long t_quads = __builtin_amdgcn_s_memrealtime();
 
     // ---- 4. deferred shading + finalise (kernels_shade.h; obj/core.py:640)
@@ -569,11 +617,12 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     }
     if (tid < BIN_CLASSES) ta.bin_count[tid * n_tiles + tile] = 0;   // cursors zeroed for the next frame
     if (tid == 0) {                                       // what the slot's next frame should know about this tile
-        const int cls = cost >= 900u ? 0 : cost >= 400u ? 1 : cost >= 150u ? 2 : -1;
+        // heaviest class: where tiles are split, those whose quad walk is worth sharing; else simply the slowest
+        int cls = (SPLIT ? (cost >= 600u && n_quad_raw >= 32u) : cost >= 900u) ? 0 : cost >= 400u ? 1 : cost >= 150u ? 2 : -1;
         uint8_t flag = 0;
-        if (cls >= 0) {
+        for (; cls >= 0 && cls < HEAVY_CLASSES && !flag; ++cls) {     // a full list hands the tile down to the next one
             const uint32_t at = atomicAdd(&ta.next_hist->count[cls], 1u);
-            if (at < (uint32_t)HEAVY_MAX) { ta.next_hist->tiles[cls][at] = (uint32_t)tile; flag = 1; }
+            if (at < (uint32_t)(cls == 0 ? HEAVY0_MAX : HEAVY_MAX)) { ta.next_hist->tiles[cls][at] = (uint32_t)tile; flag = 1; }
             else atomicSub(&ta.next_hist->count[cls], 1u);
         }
         ta.next_heavy_flag[tile] = flag;

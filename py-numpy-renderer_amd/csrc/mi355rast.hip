@@ -87,7 +87,7 @@ constexpr int EVENT_RING = 64, N_MARKS = 6;
 struct FrameSlot {
     hipStream_t stream = nullptr;                 // the stream this slot serves
     DevBuf d_vout, d_vclip, d_tris, d_attrs, d_clips, d_status, d_count_list, d_quads, d_sil, d_counters;
-    DevBuf d_bin_count, d_items[mr::BIN_CLASSES], d_work, d_tile_stats, d_hist, d_heavy_flag;
+    DevBuf d_bin_count, d_items[mr::BIN_CLASSES], d_work, d_tile_stats, d_hist, d_heavy_flag, d_split;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
     // capacities this slot's buffers were last bound with (the scene holds the current ones)
     uint32_t bin_cap[mr::BIN_CLASSES] = { 0, 0, 0 }, work_cap = 0, quad_cap = 0;
@@ -108,7 +108,7 @@ struct FrameSlot {
     void release()
     {
         DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_attrs, &d_clips, &d_status, &d_quads, &d_sil, &d_counters,
-                           &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_heavy_flag,
+                           &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_heavy_flag, &d_split,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
         if (events_ok) {
@@ -465,6 +465,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     // frame's k_tile, so a steady-state frame issues no memset; only a new tile grid needs one.
     HIP_TRY(fs->d_hist.ensure(2 * sizeof(TileHistory)));
     HIP_TRY(fs->d_heavy_flag.ensure(2 * (size_t)std::max(n_tiles, 1)));
+    {
+        // split tiles: HEAVY0_MAX arrival counters (zero between frames), then the parts' stencil counts
+        const void *had = fs->d_split.p;
+        HIP_TRY(fs->d_split.ensure((size_t)HEAVY0_MAX * 4 + (size_t)HEAVY0_MAX * HEAVY_SPLIT * TILE_PX * 4));
+        if (fs->d_split.p != had) HIP_TRY(hipMemsetAsync(fs->d_split.p, 0, (size_t)HEAVY0_MAX * 4, stream));
+    }
     if (fs->bins_zeroed_for != BIN_CLASSES * n_tiles + 1) {
         HIP_TRY(hipMemsetAsync(fs->d_bin_count.p, 0, fs->d_bin_count.cap, stream));
         HIP_TRY(hipMemsetAsync(fs->d_hist.p, 0, fs->d_hist.cap, stream));       // no history for a new tile grid
@@ -535,6 +541,10 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ta.tile_stats = fs->d_tile_stats.as<uint32_t>();
     ta.ctr = ctr; ta.next_ctr = next_ctr;
     ta.hist = hist; ta.next_hist = next_hist;
+    // a device whose tiles all fit on the chip at once (a rank of a multi-GPU split) shares out the quads of
+    // its heaviest tiles: there the launch lasts as long as the slowest tile (see HEAVY_SPLIT)
+    ta.split_arrive = fs->d_split.as<uint32_t>();
+    ta.split_sten = fs->d_split.as<int32_t>() + HEAVY0_MAX;
     ta.heavy_flag = fs->d_heavy_flag.as<uint8_t>() + (size_t)par * std::max(n_tiles, 1);
     ta.next_heavy_flag = fs->d_heavy_flag.as<uint8_t>() + (size_t)(par ^ 1u) * std::max(n_tiles, 1);
     ShadeArgs sh;
@@ -544,8 +554,10 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sh.gamma_lut = sc->d_gamma.as<float>();
     sh.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
     sh.out = d_out;
-    if (n_tiles > 0)
-        hipLaunchKernelGGL(k_tile, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
+    if (n_tiles > 0 && n_tiles <= 2048)
+        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
+    else if (n_tiles > 0)
+        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
     else          // nothing to draw on this device (a stripe beyond the frame): still hand the counters on
         HIP_TRY(hipMemsetAsync(next_ctr, 0, sizeof(Counters), stream));
     if (timing) HIP_TRY(hipEventRecord(fs->ev[4], stream));
