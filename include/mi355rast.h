@@ -265,6 +265,11 @@ int mr_read_silhouette(mr_scene *scene, int32_t *out_triples, int32_t cap);
 #define MR_TILE_RECORD_WORDS 12
 int mr_debug_read_tile_records(mr_scene *scene, uint32_t *out, int32_t cap_tiles);
 
+/* Diagnostics: the order in which the most recent frame's tile kernel took its tiles (entry b = the tile
+ * of workgroup b): heaviest first by the estimate the slot's previous frame left, row-major for a first
+ * frame or a new tile grid.  Always a permutation of 0 .. n_tiles-1.  Returns the number of tiles. */
+int mr_debug_read_tile_order(mr_scene *scene, uint32_t *out, int32_t cap_tiles);
+
 /* Human-readable description of the last error on this thread ("" if none). */
 const char *mr_last_error(void);
 

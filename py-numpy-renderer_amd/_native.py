@@ -100,6 +100,7 @@ _PROTOTYPES = {
     "mr_read_face_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_silhouette": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_debug_read_tile_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "mr_debug_read_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_last_error": (C.c_char_p, []),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
@@ -503,6 +504,13 @@ class DeviceRenderer:
                    "mr_debug_read_tile_records")
         out = np.empty((max(n, 1), TILE_RECORD_WORDS), dtype=np.uint32)
         _check(self.lib.mr_debug_read_tile_records(self.handle, out.ctypes.data, n), "mr_debug_read_tile_records")
+        return out[:n]
+
+    def read_tile_order(self):
+        """The order in which the last frame's tile kernel took its tiles: (n_tiles,) uint32."""
+        n = _check(self.lib.mr_debug_read_tile_order(self.handle, (C.c_uint32 * 1)(), 0), "mr_debug_read_tile_order")
+        out = np.empty(max(n, 1), dtype=np.uint32)
+        _check(self.lib.mr_debug_read_tile_order(self.handle, out.ctypes.data, n), "mr_debug_read_tile_order")
         return out[:n]
 
     def read_face_status(self):

@@ -79,6 +79,22 @@ k_edge_normals(int n_edges, EdgeRec *__restrict__ edges, const double *__restric
     edges[e] = r;
 }
 
+// EdgeRec[] -> EdgeRec32[] in place is not possible (overlap): into a second buffer, once per commit.
+__global__ void __launch_bounds__(256)
+k_edge_compact(int n_edges, const EdgeRec *__restrict__ edges, EdgeRec32 *__restrict__ out)
+{
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= n_edges) return;
+    const EdgeRec r = edges[e];
+    EdgeRec32 c;
+    c.inc[0] = r.inc[0]; c.inc[1] = r.inc[1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.n[i][j] = (float)r.n[i][j];
+    out[e] = c;
+}
+
 // One face corner through obj/triangular.py:36-45: clip = v @ MVP (and @ debug MVP), depth =
 // 1 / clip.w, ndc = clip * depth, screen = ndc @ viewport; plus linearize_z of the screen z.
 struct CornerOut {
@@ -234,13 +250,14 @@ struct SetupArgs {
     uint8_t *status;
     uint32_t *count_list;            // faces whose survivor count needs a wavefront (k_bin_work)
     Counters *ctr;
-    const EdgeRec *edges;            // static unique-edge table
+    const uint8_t *tile_class;       // what the slot's previous frame left (kernels_tile.h, tile_class) ...
+    uint32_t *order;                 // ... and the tile order made of it for this frame's tile kernel
+    const EdgeRec *edges;            // static unique-edge table (EdgeRec32[] when fc.edge_compact)
     const uint32_t *edge_inc;        // incidences beyond an edge's first two
     const double *face_n;            // static face normals (for those)
     int32_t *sil_edges;              // (quad_cap, 2): face, corner of each silhouette edge
     QuadRec *quads;
     uint32_t quad_cap;
-    uint32_t *clear4;                // four words this launch clears for the frame's tile kernel (its tile-history counts)
 };
 
 // One face: status, TriRec / TriAttr / TriClip.  Returns bit 0 = the face goes on to the tile
@@ -702,7 +719,18 @@ __device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs
     bool sil = false;
     uint32_t last = 0;
     if (e < fc.n_edges) {
-        const EdgeRec r = sa.edges[e];
+        EdgeRec r;
+        if (fc.edge_compact) {
+            const EdgeRec32 c = reinterpret_cast<const EdgeRec32 *>(sa.edges)[e];
+            r.inc[0] = c.inc[0]; r.inc[1] = c.inc[1];
+            r.extra_off = r.extra_cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) r.n[i][j] = (double)c.n[i][j];
+        } else {
+            r = sa.edges[e];
+        }
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -747,14 +775,16 @@ __device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs
     }
 }
 
-// First launch of the frame: workgroups [0, face_blocks) set faces up, the rest look at edges.
+// First launch of the frame: workgroup 0 puts the frame's tiles in order (a serial walk of some microseconds,
+// hidden behind the others), workgroups [1, 1 + face_blocks) set faces up, the rest look at edges.
 template <bool PRE_XFORM>
 __global__ void __launch_bounds__(SETUP_BLOCK, 4)
 k_setup(const FrameConst fc, const SetupArgs sa, const BinArgs bins, uint32_t face_blocks)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 4) sa.clear4[threadIdx.x] = 0;    // a memset would be a launch of its own
-    if (blockIdx.x < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, blockIdx.x);
-    else edge_block(fc, sa, bins, blockIdx.x - face_blocks);
+    if (blockIdx.x == 0) { order_tiles_block(sa.tile_class, sa.order, fc.tiles_x * fc.tiles_y); return; }
+    const uint32_t b = blockIdx.x - 1;
+    if (b < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, b);
+    else edge_block(fc, sa, bins, b - face_blocks);
 }
 
 // Second launch: the leftover survivor counts (a few workgroups, first so that their

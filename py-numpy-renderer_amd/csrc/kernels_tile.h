@@ -112,21 +112,28 @@ static_assert(sizeof(QuadHead) == 64, "QuadHead mirrors QuadRec's header");
 constexpr int MAT_LDS = 8;            // scenes with up to this many materials keep them in LDS
 static_assert(sizeof(Material) % 8 == 0 && MAT_LDS * sizeof(Material) / 8 <= TILE_PX, "material staging");
 
-// Heavy tiles first.  A frame's time is the slowest tile's: a tile under the mesh AND its shadow
-// volume takes 10-30x the time of a floor tile, and in plain row-major order those tiles start
-// in the middle of the launch and finish 40 us after everything else.  Frames of a sequence
-// resemble each other, so every tile leaves an estimate of its cost for the slot's NEXT frame:
-// tiles above a threshold enter one of HEAVY_CLASSES lists (heaviest class first) and are flagged.
-// The next frame's launch starts with HEAVY_FRONT extra workgroups: workgroup b of those renders
-// entry b of the lists (or exits at once if there is none), and the workgroup that owns a flagged
-// tile exits at once.  Every tile is rendered exactly once whatever the lists say, so a stale
-// history (scene or camera changed) costs time, never correctness; a new tile grid starts with an
-// empty history.  (A loop "list entry, then own tile" inside one workgroup doubled the kernel's
-// register budget: the compiler hoists the frame constants' register copies out of the loop.)
-constexpr int HEAVY_CLASSES = 3, HEAVY_MAX = 512;
+// Heaviest tiles first.  A tile under the mesh AND its shadow volume takes 10-80x the time of a floor
+// tile.  In plain row-major order such tiles start in the middle of the launch and finish 40 us after
+// everything else, and even with only the heaviest moved to the front the launch ended on the 10-20 us
+// tiles that happened to start last.  Frames of a sequence resemble each other, so every tile leaves the
+// class of its estimated cost (one byte, a plain store) for the slot's NEXT frame, whose k_bin_work sorts
+// the tiles by class (order_tiles_block in kernels_bin.h: a counting sort in one workgroup, beside the
+// binning) and whose tile workgroup b renders entry b of that order: longest-processing-time first.  The
+// order is a permutation of the tiles by construction, and a grid with any tile of unknown class (a first
+// frame, a new tile grid) is rendered in row-major order: a stale history costs time, never correctness.
+// (A loop "list entry, then own tile" inside one workgroup doubled the kernel's register budget -- the
+// compiler hoists the frame constants' register copies out of it; per-class lists appended to with atomics
+// held every workgroup for the 2 us of a device-scope atomic's round trip: 82 -> 119 us.)
+// cost thresholds of classes 1..7 (tile_cost units, ~0.1 us); the rest is class 8
+__device__ __forceinline__ int tile_class(uint32_t cost)
+{
+    return cost >= 900u ? 1 : cost >= 600u ? 2 : cost >= 400u ? 3 : cost >= 250u ? 4 : cost >= 150u ? 5 : cost >= 90u ? 6
+         : cost >= 45u ? 7 : 8;
+}
+static_assert(ORDER_CLASSES == 8, "tile_class");
 // On a device that owns few tiles (a rank of a multi-GPU split: all its tiles are resident at once and
 // the launch lasts as long as its slowest tile) the heaviest class is not only started first: those
-// tiles' shadow quads -- walked one after the other, 0.4 us each, up to a hundred and more where a mesh's
+// tiles' shadow quads -- walked one after the other, up to a hundred and more where a mesh's
 // outline and its shadow volume overlap -- are SHARED OUT over HEAVY_SPLIT workgroups.  Each of them
 // rasterises the tile (same lists, same order-free arithmetic: the same z and winners), counts its share
 // of the quads, and leaves its stencil counts in a scratch slot; the workgroup that arrives last (a
@@ -135,11 +142,7 @@ constexpr int HEAVY_CLASSES = 3, HEAVY_MAX = 512;
 // frame the launch is bound by the tiles' total work, which the repeated rasterisation only adds to
 // (measured on MI355X, c4: 86 -> 90 us whole frame; a rank of 8: 56 -> 38 us).
 constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = 128;
-constexpr int HEAVY_FRONT = HEAVY_SPLIT * HEAVY0_MAX + (HEAVY_CLASSES - 1) * HEAVY_MAX;
-struct TileHistory {
-    uint32_t count[HEAVY_CLASSES + 1];
-    uint32_t tiles[HEAVY_CLASSES][HEAVY_MAX];
-};
+constexpr int SPLIT_FRONT = HEAVY_SPLIT * HEAVY0_MAX;     // extra workgroups of a k_tile<true> launch
 
 // estimated cost of a tile in ~0.1 us from its list lengths (fitted to measured tile times on MI355X)
 __device__ __forceinline__ uint32_t tile_cost(uint32_t n_small, uint32_t n_big, uint32_t n_quad)
@@ -159,10 +162,8 @@ struct TileArgs {
     Counters *ctr, *next_ctr;     // this frame's counters; the next frame's (cleared here)
     int32_t *split_sten;          // [HEAVY0_MAX][HEAVY_SPLIT][TILE_PX] stencil counts of a split tile's parts
     uint32_t *split_arrive;       // [HEAVY0_MAX] parts that have left theirs (zero between frames)
-    const TileHistory *hist;      // what the slot's previous frame learnt about its tiles
-    TileHistory *next_hist;       // what this frame leaves for the next
-    const uint8_t *heavy_flag;    // [n_tiles] != 0: the tile is in hist's lists
-    uint8_t *next_heavy_flag;
+    const uint32_t *order;        // ORDER_HEAD words, then the tiles in the order to render them (k_bin_work); null: row-major
+    uint8_t *tile_class;          // [n_tiles] what this frame leaves for the next: 1 + the tile's cost class
 };
 
 // One workgroup per tile, one pixel per thread.  Tiles are dealt to workgroups in plain
@@ -183,31 +184,29 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int n_tiles = fc.tiles_x * fc.tiles_y;
-    if ((int)blockIdx.x >= n_tiles + HEAVY_FRONT) return;
     const bool rh = fc.system == 1;
     const bool counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
     const TriRec *__restrict__ tris = sh.tris;
 
-    if (blockIdx.x == (uint32_t)HEAVY_FRONT && tid == 0) *ta.next_ctr = Counters{};  // nobody touches the next frame's counters before this kernel ends
+    if (blockIdx.x == 0 && tid == 0) *ta.next_ctr = Counters{};  // nobody touches the next frame's counters before this kernel ends
 
-    // heavy tiles first (see TileHistory): entry blockIdx.x of the previous frame's lists, then the own tile
-    const uint32_t h0 = min(ta.hist->count[0], (uint32_t)HEAVY0_MAX), n1 = min(ta.hist->count[1], (uint32_t)HEAVY_MAX),
-                   n2 = min(ta.hist->count[2], (uint32_t)HEAVY_MAX);
-    int tile, part = 0, n_parts = 1, entry = 0;
-    if (blockIdx.x < (uint32_t)(HEAVY_SPLIT * HEAVY0_MAX)) {
-        entry = (int)blockIdx.x / HEAVY_SPLIT;
-        part = (int)blockIdx.x % HEAVY_SPLIT;
-        n_parts = (SPLIT && !counters) ? HEAVY_SPLIT : 1;
-        if (entry >= (int)h0 || part >= n_parts) return;
-        tile = (int)ta.hist->tiles[0][entry];
-    } else if (blockIdx.x < (uint32_t)HEAVY_FRONT) {
-        const uint32_t b = blockIdx.x - (uint32_t)(HEAVY_SPLIT * HEAVY0_MAX);
-        if (b >= n1 + n2) return;
-        tile = (int)(b < n1 ? ta.hist->tiles[1][b] : ta.hist->tiles[2][b - n1]);
-    } else {
-        tile = (int)blockIdx.x - HEAVY_FRONT;
-        if (ta.heavy_flag[tile]) return;
+    // heaviest tiles first: entry blockIdx.x of the order k_bin_work left (see tile_class)
+    uint32_t idx = blockIdx.x;
+    int tile = 0, part = 0, n_parts = 1, entry = 0;
+    if (SPLIT) {
+        const uint32_t n0 = ta.order ? min(ta.order[0], (uint32_t)HEAVY0_MAX) : 0u;   // the class whose quads are shared out
+        if (idx < (uint32_t)SPLIT_FRONT) {
+            entry = (int)idx / HEAVY_SPLIT;
+            part = (int)idx % HEAVY_SPLIT;
+            n_parts = counters ? 1 : HEAVY_SPLIT;
+            if (entry >= (int)n0 || part >= n_parts) return;
+            idx = (uint32_t)entry;
+        } else {
+            idx = idx - (uint32_t)SPLIT_FRONT + n0;
+        }
     }
+    if (idx >= (uint32_t)n_tiles) return;
+    tile = ta.order ? (int)ta.order[ORDER_HEAD + idx] : (int)idx;
     const int ltr = tile / fc.tiles_x;                    // local tile row
     const int gx = (tile % fc.tiles_x) * TILE_W, gy = tile_row_frame(fc, ltr) * TILE_H;
     const int lp = tid;                                   // pixel of this thread inside the tile
@@ -233,6 +232,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     // the host has finalised already.  Shadow quads over it only matter to the counters.
     if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (fc.background_u8 >> 24) &&
         !((fc.flags & MR_FRAME_SKYBOX) && sh.sky) && !sh.frame && !ta.zbuf) {
+        if (part != 0) return;                            // (a tile that was heavy a frame ago: one part will do)
         if (live) {
             uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
             o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
@@ -244,7 +244,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
             rec[8] = rec[10] = rec[11] = (uint32_t)t_start;
             rec[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
             ta.bin_count[2 * n_tiles + tile] = 0;
-            ta.next_heavy_flag[tile] = 0;
+            ta.tile_class[tile] = (uint8_t)ORDER_CLASSES;
         }
         return;
     }
@@ -617,15 +617,10 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     }
     if (tid < BIN_CLASSES) ta.bin_count[tid * n_tiles + tile] = 0;   // cursors zeroed for the next frame
     if (tid == 0) {                                       // what the slot's next frame should know about this tile
-        // heaviest class: where tiles are split, those whose quad walk is worth sharing; else simply the slowest
-        int cls = (SPLIT ? (cost >= 600u && n_quad_raw >= 32u) : cost >= 900u) ? 0 : cost >= 400u ? 1 : cost >= 150u ? 2 : -1;
-        uint8_t flag = 0;
-        for (; cls >= 0 && cls < HEAVY_CLASSES && !flag; ++cls) {     // a full list hands the tile down to the next one
-            const uint32_t at = atomicAdd(&ta.next_hist->count[cls], 1u);
-            if (at < (uint32_t)(cls == 0 ? HEAVY0_MAX : HEAVY_MAX)) { ta.next_hist->tiles[cls][at] = (uint32_t)tile; flag = 1; }
-            else atomicSub(&ta.next_hist->count[cls], 1u);
-        }
-        ta.next_heavy_flag[tile] = flag;
+        int cls = tile_class(cost);
+        // where tiles are split, class 1 holds those whose quad walk is worth sharing
+        if (SPLIT) cls = (cost >= 600u && n_quad_raw >= 32u) ? 1 : cls < 2 ? 2 : cls;
+        ta.tile_class[tile] = (uint8_t)cls;
     }
 }
 

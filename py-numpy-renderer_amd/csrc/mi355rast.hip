@@ -87,7 +87,7 @@ constexpr int EVENT_RING = 64, N_MARKS = 6;
 struct FrameSlot {
     hipStream_t stream = nullptr;                 // the stream this slot serves
     DevBuf d_vout, d_vclip, d_tris, d_attrs, d_clips, d_status, d_count_list, d_quads, d_sil, d_counters;
-    DevBuf d_bin_count, d_items[mr::BIN_CLASSES], d_work, d_tile_stats, d_hist, d_heavy_flag, d_split;
+    DevBuf d_bin_count, d_items[mr::BIN_CLASSES], d_work, d_tile_stats, d_hist, d_split;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
     // capacities this slot's buffers were last bound with (the scene holds the current ones)
     uint32_t bin_cap[mr::BIN_CLASSES] = { 0, 0, 0 }, work_cap = 0, quad_cap = 0;
@@ -98,6 +98,7 @@ struct FrameSlot {
     uint8_t ev_marks[EVENT_RING] = {};            // 0: the frame recorded no events, 1: frame + tile kernel, 2: every stage
     hipEvent_t *ev = ev_ring[0];
     uint64_t frames_enqueued = 0;
+    uint64_t last_serial = 0;                // the scene's frame serial when this slot last took a frame
     bool events_ok = false;
 
     mr_frame_desc last_frame = {};
@@ -108,7 +109,7 @@ struct FrameSlot {
     void release()
     {
         DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_attrs, &d_clips, &d_status, &d_quads, &d_sil, &d_counters,
-                           &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_heavy_flag, &d_split,
+                           &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_split,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
         if (events_ok) {
@@ -143,6 +144,8 @@ struct mr_scene {
 
     // ---- device copies of the static scene
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edges, d_edge_inc, d_face_n;
+    DevBuf d_edges32;                        // the compact edge table, when the scene allows it
+    bool edge_compact = false;
     DevBuf d_ov_seg_first, d_ov_seg_count, d_ov_target, d_ov_next, d_ov_z, d_ov_touched, d_ov_keep, d_ov_blend;
     int32_t ov_segments = 0, ov_points = 0, ov_touched = 0, ov_max_target = -1;     // debug-frustum overlay statement lists
     DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
@@ -152,6 +155,7 @@ struct mr_scene {
     // ---- frame slots, one per stream that has rendered this scene
     std::vector<std::unique_ptr<FrameSlot>> slots;
     FrameSlot *last = nullptr;               // slot of the most recently enqueued frame
+    uint64_t frame_serial = 0;               // frames enqueued on any stream
     mr_stats stats = {};
     int n_silhouette = 0;
     // Capacities of the per-frame work lists, shared by all slots: what one frame learnt (a tile with
@@ -285,6 +289,14 @@ int commit(mr_scene *sc)
     if (ne > 0)
         hipLaunchKernelGGL(mr::k_edge_normals, dim3((ne + 255) / 256), dim3(256), 0, g_stream, ne, sc->d_edges.as<mr::EdgeRec>(),
                            sc->d_face_n.as<double>());
+    // compact edge records when every model's vertices are float32 and no edge has more than two faces
+    sc->edge_compact = ne > 0 && sc->edge_inc.empty();
+    for (uint8_t ff : sc->face_flags) if (!(ff & mr::FF_VERTS_F32)) { sc->edge_compact = false; break; }
+    if (sc->edge_compact) {
+        HIP_TRY(sc->d_edges32.ensure((size_t)ne * sizeof(mr::EdgeRec32)));
+        hipLaunchKernelGGL(mr::k_edge_compact, dim3((ne + 255) / 256), dim3(256), 0, g_stream, ne, sc->d_edges.as<mr::EdgeRec>(),
+                           sc->d_edges32.as<mr::EdgeRec32>());
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g_stream));
     sc->dirty = false;
@@ -369,6 +381,7 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
     fc.has_no_depth = 0;
     for (uint8_t ff : sc->face_flags) if (ff & mr::FF_NO_DEPTH) { fc.has_no_depth = 1; break; }
     fc.same_clip = memcmp(fr->mvp, fr->debug_mvp, sizeof(fr->mvp)) == 0 ? 1 : 0;
+    fc.edge_compact = sc->edge_compact ? 1 : 0;
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
     fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;
@@ -463,8 +476,9 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     if (timing) HIP_TRY(hipEventRecord(fs->ev[0], stream));
     // The list cursors are left zeroed by k_tile and the frame counters are cleared by the previous
     // frame's k_tile, so a steady-state frame issues no memset; only a new tile grid needs one.
-    HIP_TRY(fs->d_hist.ensure(2 * sizeof(TileHistory)));
-    HIP_TRY(fs->d_heavy_flag.ensure(2 * (size_t)std::max(n_tiles, 1)));
+    // tile order: ORDER_HEAD + n_tiles words (written by k_bin_work), then the tiles' class bytes (k_tile, for the next frame)
+    const size_t order_bytes = (((size_t)ORDER_HEAD + (size_t)std::max(n_tiles, 1)) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    HIP_TRY(fs->d_hist.ensure(order_bytes + (size_t)std::max(n_tiles, 1) + 16));     // class bytes: 16-byte aligned, padded
     {
         // split tiles: HEAVY0_MAX arrival counters (zero between frames), then the parts' stencil counts
         const void *had = fs->d_split.p;
@@ -474,14 +488,10 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     if (fs->bins_zeroed_for != BIN_CLASSES * n_tiles + 1) {
         HIP_TRY(hipMemsetAsync(fs->d_bin_count.p, 0, fs->d_bin_count.cap, stream));
         HIP_TRY(hipMemsetAsync(fs->d_hist.p, 0, fs->d_hist.cap, stream));       // no history for a new tile grid
-        HIP_TRY(hipMemsetAsync(fs->d_heavy_flag.p, 0, fs->d_heavy_flag.cap, stream));
         fs->bins_zeroed_for = BIN_CLASSES * n_tiles + 1;
     }
-    const unsigned par = (unsigned)(fs->frames_enqueued & 1);
-    TileHistory *hist = fs->d_hist.as<TileHistory>() + par, *next_hist = fs->d_hist.as<TileHistory>() + (par ^ 1u);
-    // this frame's tile kernel fills next_hist; its counts are cleared first, by k_setup (the previous
-    // frame is done reading it)
-    static_assert(sizeof(next_hist->count) == 16, "k_setup clears four words");
+    uint32_t *order = fs->d_hist.as<uint32_t>();
+    uint8_t *tile_class = reinterpret_cast<uint8_t *>(fs->d_hist.p) + order_bytes;
 
     BinArgs ba;
     ba.tris = fs->d_tris.as<TriRec>(); ba.quads = fs->d_quads.as<QuadRec>();
@@ -496,9 +506,9 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.vout = fs->d_vout.as<VertexOut>(); sa.vclip = fs->d_vclip.as<VertexClip>();
     sa.tris = fs->d_tris.as<TriRec>(); sa.attrs = fs->d_attrs.as<TriAttr>(); sa.clips = fs->d_clips.as<TriClip>();
     sa.status = fs->d_status.as<uint8_t>(); sa.count_list = fs->d_count_list.as<uint32_t>(); sa.ctr = ctr;
-    sa.edges = sc->d_edges.as<EdgeRec>(); sa.edge_inc = sc->d_edge_inc.as<uint32_t>(); sa.face_n = sc->d_face_n.as<double>();
+    sa.edges = sc->edge_compact ? reinterpret_cast<const EdgeRec *>(sc->d_edges32.p) : sc->d_edges.as<EdgeRec>(); sa.edge_inc = sc->d_edge_inc.as<uint32_t>(); sa.face_n = sc->d_face_n.as<double>();
+    sa.tile_class = tile_class; sa.order = order;
     sa.sil_edges = fs->d_sil.as<int32_t>(); sa.quads = fs->d_quads.as<QuadRec>(); sa.quad_cap = fs->quad_cap;
-    sa.clear4 = next_hist->count;
 
     // ---- 1. set-up: faces and (with shadows) edges, one launch
     if (vertex_mfma && fc.n_vertices > 0)
@@ -508,14 +518,10 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     {
         const unsigned face_blocks = fc.n_faces > 0 ? blocks_for(fc.n_faces, SETUP_BLOCK) : 0u;
         const unsigned edge_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, SETUP_BLOCK) : 0u;
-        if (face_blocks + edge_blocks > 0) {
-            if (vertex_mfma)
-                hipLaunchKernelGGL(k_setup<true>, dim3(face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
-            else
-                hipLaunchKernelGGL(k_setup<false>, dim3(face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
-        } else {
-            HIP_TRY(hipMemsetAsync(next_hist->count, 0, sizeof(next_hist->count), stream));
-        }
+        if (vertex_mfma)
+            hipLaunchKernelGGL(k_setup<true>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
+        else
+            hipLaunchKernelGGL(k_setup<false>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
 
@@ -540,13 +546,27 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ta.stencil = keep ? fs->d_stencil.as<int32_t>() : nullptr;
     ta.tile_stats = fs->d_tile_stats.as<uint32_t>();
     ta.ctr = ctr; ta.next_ctr = next_ctr;
-    ta.hist = hist; ta.next_hist = next_hist;
+    // Heaviest-first order shortens the critical path of a frame that has the device to itself.  When the
+    // scene is being rendered from several streams at once (frames in flight), the next frame's work fills
+    // the tail anyway and bunching the heavy tiles at the front only makes them compete: measured on MI355X
+    // with three streams, row-major is 4 % (c4) to 28 % (c2) faster per frame, and 10 % slower for a lone
+    // frame.  So: ordered when no other stream took one of the scene's last frames.
+    // MR_TILE_ORDER=rowmajor | heaviest forces either (for the ablation in DESIGN.md).
+    static const int order_mode = [] {
+        const char *e = getenv("MR_TILE_ORDER");
+        return !e ? 0 : !strcmp(e, "rowmajor") ? 1 : !strcmp(e, "heaviest") ? 2 : 0;
+    }();
+    sc->frame_serial += 1;
+    bool alone = true;
+    for (auto &s : sc->slots)
+        if (s.get() != fs && s->have_frame && sc->frame_serial - s->last_serial <= 8) alone = false;
+    fs->last_serial = sc->frame_serial;
+    const bool ordered = order_mode == 2 || (order_mode == 0 && alone);
+    ta.order = ordered ? order : nullptr; ta.tile_class = tile_class;
     // a device whose tiles all fit on the chip at once (a rank of a multi-GPU split) shares out the quads of
     // its heaviest tiles: there the launch lasts as long as the slowest tile (see HEAVY_SPLIT)
     ta.split_arrive = fs->d_split.as<uint32_t>();
     ta.split_sten = fs->d_split.as<int32_t>() + HEAVY0_MAX;
-    ta.heavy_flag = fs->d_heavy_flag.as<uint8_t>() + (size_t)par * std::max(n_tiles, 1);
-    ta.next_heavy_flag = fs->d_heavy_flag.as<uint8_t>() + (size_t)(par ^ 1u) * std::max(n_tiles, 1);
     ShadeArgs sh;
     sh.tris = fs->d_tris.as<TriRec>(); sh.attrs = fs->d_attrs.as<TriAttr>();
     sh.materials = sc->d_materials.as<Material>();
@@ -555,9 +575,9 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sh.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
     sh.out = d_out;
     if (n_tiles > 0 && n_tiles <= 2048)
-        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
+        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + SPLIT_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
     else if (n_tiles > 0)
-        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)(n_tiles + HEAVY_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
+        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc, ta, sh);
     else          // nothing to draw on this device (a stripe beyond the frame): still hand the counters on
         HIP_TRY(hipMemsetAsync(next_ctr, 0, sizeof(Counters), stream));
     if (timing) HIP_TRY(hipEventRecord(fs->ev[4], stream));
@@ -740,7 +760,7 @@ void mr_scene_destroy(mr_scene *sc)
     if (!sc) return;
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
-                       &sc->d_textures, &sc->d_edges, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma,
+                       &sc->d_textures, &sc->d_edges, &sc->d_edges32, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma,
                        &sc->d_ov_seg_first, &sc->d_ov_seg_count, &sc->d_ov_target, &sc->d_ov_next, &sc->d_ov_z,
                        &sc->d_ov_touched, &sc->d_ov_keep, &sc->d_ov_blend };
     for (DevBuf *b : bufs) b->release();
@@ -1106,6 +1126,18 @@ int mr_debug_read_tile_records(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
     HIP_TRY(hipDeviceSynchronize());
     static_assert(mr::TILE_REC == MR_TILE_RECORD_WORDS, "tile record size is part of the ABI");
     if (n > 0) HIP_TRY(hipMemcpy(out, fs->d_tile_stats.p, (size_t)n * mr::TILE_REC * 4, hipMemcpyDeviceToHost));
+    return fs->last_n_tiles;
+}
+
+int mr_debug_read_tile_order(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
+{
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    if (!out) return fail(MR_E_INVALID, "NULL argument");
+    const int n = std::min(fs->last_n_tiles, cap_tiles);
+    HIP_TRY(hipDeviceSynchronize());
+    if (n > 0)
+        HIP_TRY(hipMemcpy(out, fs->d_hist.as<uint32_t>() + mr::ORDER_HEAD, (size_t)n * 4, hipMemcpyDeviceToHost));
     return fs->last_n_tiles;
 }
 

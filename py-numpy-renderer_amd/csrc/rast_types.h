@@ -51,6 +51,7 @@ struct FrameConst {
     int32_t out_tile_rows;       // > 0: striped output layout with this many tile rows per device (see out_row)
     int32_t n_vertices, n_faces, n_edges, n_materials;
     int32_t same_clip;           // debug_mvp == mvp bit for bit: the second clip test repeats the first
+    int32_t edge_compact;        // the scene's edge table is EdgeRec32[] (else EdgeRec[])
     double mvp[16], viewport[16], debug_mvp[16];
     double planes[24];
     double two_nf, f_plus_n, f_minus_n;      // linearize_z constants (obj/core.py:226-228)
@@ -138,6 +139,14 @@ struct alignas(16) EdgeRec {
     double n[2][3];
 };
 static_assert(sizeof(EdgeRec) == 64, "EdgeRec layout");
+// The compact form, used when every model's vertices are float32 (then the normals ARE float32 values,
+// core.py:127-130) and no edge has more than two incident faces (any manifold mesh): half the bytes of
+// what is the largest stream of the set-up kernel.
+struct alignas(16) EdgeRec32 {
+    uint32_t inc[2];
+    float n[2][3];
+};
+static_assert(sizeof(EdgeRec32) == 32, "EdgeRec32 layout");
 
 struct Texture {
     const float *rgb;

@@ -105,6 +105,35 @@ def test_render_is_repeatable_and_matches_scene_render(api):
     scene.close()
 
 
+@pytest.mark.parametrize("name,shadows", [("c3_diablo_floor_1080p", True), ("diablo_small", True), ("kat_house", False)])
+def test_heaviest_first_tile_order_is_a_permutation(api, name, shadows):
+    """The tile kernel takes its tiles heaviest first, by what the previous frame on the slot learnt: the
+    first frame's order is row-major, later ones are permutations sorted by cost class, and the frame does
+    not depend on the order (kernels_tile.h tile_class, kernels_bin.h order_tiles_block)."""
+    scene = scenes.build(api, name)
+    backend = scene._backend()
+    first = backend.render(scene, shadows=shadows).copy()
+    n = len(backend.read_tile_order())       # (row-major, unless growing a work list made this a second attempt)
+    rec = backend.read_tile_records().astype(np.int64)
+    cost = 30 + 3 * rec[:, 5] + 15 * rec[:, 6] + 6 * rec[:, 7]
+    cls = np.digitize(-cost, [-900, -600, -400, -250, -150, -90, -45], right=True)        # 0 = heaviest
+    if n <= 2048:       # few tiles: the first class is "quads worth sharing out" (kernels_tile.h HEAVY_SPLIT)
+        cls = np.where((cost >= 600) & (rec[:, 7] >= 32), 0, np.maximum(cls, 1))
+    for _ in range(2):
+        again = backend.render(scene, shadows=shadows)
+        order = backend.read_tile_order().astype(np.int64)
+        assert np.array_equal(np.sort(order), np.arange(n))
+        assert (np.diff(cls[order]) >= 0).all()
+        assert np.array_equal(again, first)
+        assert np.array_equal(backend.read_tile_records().astype(np.int64)[:, 5:8], rec[:, 5:8])
+    # a new tile grid starts in row-major order again
+    half = backend.render(scene, shadows=shadows, row_band=(0, first.shape[0] // 32 * 16))
+    assert np.array_equal(backend.read_tile_order(), np.arange(len(backend.read_tile_order()), dtype=np.uint32))
+    assert np.array_equal(half, first[:half.shape[0]])
+    assert np.array_equal(backend.render(scene, shadows=shadows, row_band=(0, first.shape[0] // 32 * 16)), half)
+    scene.close()
+
+
 @pytest.mark.parametrize("bands", [2, 3, 8])
 def test_row_bands_tile_the_frame(api, bands):
     """Screen-tile split: rendering disjoint row bands and stacking them gives the whole frame

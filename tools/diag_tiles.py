@@ -41,3 +41,8 @@ mesh = small > 0
 print("mesh tiles", mesh.sum(), "mean dur", dur[mesh].mean() if mesh.any() else 0)
 q = quads > 0
 print("quad tiles", q.sum(), "mean dur", dur[q].mean() if q.any() else 0)
+
+# least-squares fit of the tile time (0.1 us units) on the list lengths: what tile_cost should be
+A = np.stack([np.ones(len(r)), small, big, quads], 1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, dur * 10.0, rcond=None)
+print("fit dur[0.1us] = %.1f + %.2f*small + %.2f*big + %.2f*quads" % tuple(coef))
