@@ -1,0 +1,25 @@
+#!/bin/bash
+# GPU box: everything under profiles/<round>_* that depends on the kernels, in one go (about 4 GPU-minutes).
+# Results land in gpurun_out/refresh/ under their profiles/ names; copy them over afterwards:
+#   gpurun -- 'bash tools/refresh_profiles.sh r02' && cp gpurun_out/refresh/r02_* profiles/ && python tools/make_traffic_json.py r02 c4 c5
+rnd=${1:-r02}
+R=$GRAFT_REPO_ROOT/gpurun_out/refresh; rm -rf $R; mkdir -p $R
+cd $GRAFT_REPO_ROOT
+# kernel traces: the default regime (3 frames in flight) of every config, and c4 / c5 one frame at a time
+for c in c4 c5 c2 c3; do
+  bash tools/prof_bench.sh ${rnd}_$c $c > $R/${rnd}_${c}_kernel_trace_stats_default_regime.txt 2>&1 || exit 1
+  cp gpurun_out/prof/${rnd}_$c/*/*_kernel_stats.csv $R/${rnd}_${c}_default_kernel_stats.csv
+done
+for c in c4 c5; do
+  bash tools/prof_bench.sh ${rnd}_${c}_solo $c --frames-in-flight 1 > $R/${rnd}_${c}_kernel_trace_stats_one_frame_at_a_time.txt 2>&1 || exit 1
+done
+# HBM traffic per kernel (two --pmc passes each)
+bash tools/prof_traffic.sh c4_torus200k_1080p c4 > $R/${rnd}_c4_pmc_fetch_write.txt 2>&1 || exit 1
+bash tools/prof_traffic.sh c5_torus1m_4k_skybox c5 > $R/${rnd}_c5_pmc_fetch_write.txt 2>&1 || exit 1
+# SQ counters of the frame's kernels on c4 (two passes: the counters do not fit one)
+{ bash tools/prof_pmc.sh sq1 k_ SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY
+  bash tools/prof_pmc.sh sq2 k_ SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_F64; } > $R/${rnd}_c4_pmc_sq_counters.txt 2>&1 || exit 1
+# bench lines without the profiler (c4 with the CPU baseline: the line the driver records)
+for c in c2 c3 c5; do timeout -k 10 600 python bench.py --config $c --no-cpu-baseline > $R/${rnd}_bench_$c.json 2> $R/bench_$c.err || exit 1; done
+timeout -k 10 900 python bench.py > $R/${rnd}_bench_c4.json 2> $R/bench_c4.err || exit 1
+ls -la $R

@@ -15,8 +15,11 @@ shadows = name not in scenes.NO_SHADOW
 h = sc.resolution[0]
 
 
+IN_FLIGHT = int(os.environ.get("FRAMES_IN_FLIGHT", "1"))       # 1: one stream, frames back to back; 3: bench.py's default
+
+
 def per_frame(world, rank, partition, frames=300):
-    br = BandRenderer(sc, rank, world, shadows=shadows, frames_in_flight=1, partition=partition, timing_every=0)
+    br = BandRenderer(sc, rank, world, shadows=shadows, frames_in_flight=IN_FLIGHT, partition=partition, timing_every=0)
     br.world = 1                                    # this device only: no collective
     br.index = None
     for _ in range(30):
