@@ -314,12 +314,10 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         }
     };
     big_pairs(false);
+    if (n_small) { s_key[lp] = z_key(zbest); s_win[lp] = -1; }     // the small pairs' LDS z-buffer starts from the big pairs' z
     __syncthreads();                                      // s_cnt is zeroed, the LDS tables are loaded
     if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
     if (n_small) {
-        s_key[lp] = z_key(zbest);
-        __syncthreads();
-
         // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
         unsigned int sfrags = 0;
         for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
@@ -329,10 +327,10 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         if (sfrags) atomicAdd(&s_cnt[0], sfrags);
         __syncthreads();
 
-        // winners: big pairs keep their face where their z survived, then the small pairs' sweep
+        // winners: a big pair keeps its face where its z survived (an atomic like the small pairs' sweep: the
+        // largest face index among those at the final z, in any order)
         const unsigned long long kfinal = s_key[lp];
-        s_win[lp] = (best >= 0 && kfinal == z_key(zbest)) ? best : -1;
-        __syncthreads();
+        if (best >= 0 && kfinal == z_key(zbest)) atomicMax(&s_win[lp], best);
         for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
             const TriRec t = tris[small_items[i]];
             small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
