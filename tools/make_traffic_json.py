@@ -8,6 +8,7 @@ path = os.path.join(ROOT, "profiles", rnd + "_traffic.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 for tag in tags:
     raw = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc", f"traffic_{tag}", "traffic_raw.json")))
+    raw = {k.split("<")[0]: v for k, v in raw.items()}           # k_tile<false> -> k_tile
     out[tag] = {k: int((2 * v.get("fetch", 0) + v.get("write", 0)) * 1024) for k, v in raw.items() if k.startswith("k_")}
     out[tag]["_raw_kb"] = {k: {m: round(x, 2) for m, x in v.items()} for k, v in raw.items() if k.startswith("k_")}
 out["_note"] = ("HBM bytes per launch, frame-only mode as bench.py renders (tools/render_loop.py, steady state): "
