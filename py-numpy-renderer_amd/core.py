@@ -298,13 +298,42 @@ class Bound:
             return
         value.scene = instance
         if getattr(value, "show", False):
-            raise NotImplementedError(
-                "show=True gizmos need sphere.obj / camera.obj, which the reference does not ship")
+            instance.add_model(_gizmo(value))
 
     def __get__(self, instance, owner):
         if instance is None:
             return self
         return instance.__dict__.get(self._slot)
+
+
+def _gizmo(value):
+    """The little mesh that marks a ``show=True`` camera or light (``obj/core.py:532-552``): a sphere
+    for a light, a camera body for a camera, scaled to a tenth and carried to the object's place by the
+    inverse of its look-at matrix.  The meshes are loaded from ``obj_loader_test/sphere.obj`` /
+    ``obj_loader_test/camera.obj`` relative to the working directory, exactly as upstream does -- which
+    does not ship them, so without files of your own there this raises ``FileNotFoundError`` there and here.
+    Vertices and normals leave as float64 (float32 @ float64), as upstream's do; the device keeps normals
+    in float32 (the rounding is 6e-8 of a unit vector, far inside the float frame's 2e-6)."""
+    from .transformation import scale
+    is_light = isinstance(value, Light)
+    sub = Model.load_model("obj_loader_test/sphere.obj" if is_light else "obj_loader_test/camera.obj",
+                           shadowing=False)
+    sub.clip = False
+    sub = sub @ scale(0.1)
+    lookat = value.lookat
+    if is_light:            # a light straight above its centre has a singular look-at: upstream falls back to pinv
+        try:
+            sub = sub @ np.linalg.inv(lookat)
+        except np.linalg.LinAlgError:
+            sub = sub @ np.linalg.pinv(lookat)
+        try:
+            sub.normals = -sub.normals @ np.linalg.inv(lookat[mat3x3])
+        except np.linalg.LinAlgError:
+            sub.normals = -sub.normals @ np.linalg.pinv(lookat[mat3x3])
+    else:
+        sub = sub @ np.linalg.inv(lookat)
+        sub.normals = -sub.normals @ np.linalg.inv(lookat[mat3x3])
+    return sub
 
 
 class Scene:

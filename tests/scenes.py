@@ -144,6 +144,52 @@ def kat_files():
     return {k: os.path.join(GENERATED, f"{k}.obj") for k in ("kat", "kat_nouv", "kat_v_vt", "kat_v")}
 
 
+def gizmo_files():
+    """``obj_loader_test/sphere.obj`` and ``obj_loader_test/camera.obj`` for the ``show=True`` gizmos
+    (obj/core.py:532-552 loads them by these relative names; upstream does not ship them).  Returns the
+    directory to run in.  Sphere: 10 x 6 lat-long mesh of radius 1; camera: a box body with a pyramid lens."""
+    lines = []
+    nu, nv = 10, 6
+    for j in range(nv + 1):
+        th = math.pi * j / nv
+        for i in range(nu):
+            ph = 2 * math.pi * i / nu
+            lines.append("v %.6f %.6f %.6f" % (math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph)))
+    for j in range(nv + 1):
+        for i in range(nu + 1):
+            lines.append("vt %.6f %.6f" % (i / nu, 1 - j / nv))
+    for j in range(nv + 1):
+        th = math.pi * j / nv
+        for i in range(nu):
+            ph = 2 * math.pi * i / nu
+            lines.append("vn %.6f %.6f %.6f" % (math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph)))
+    vid = lambda i, j: j * nu + (i % nu) + 1
+    tid = lambda i, j: j * (nu + 1) + i + 1
+    for j in range(nv):
+        for i in range(nu):
+            quad = ((i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1))
+            tris = ([quad[0], quad[1], quad[2]] if j > 0 else []), ([quad[0], quad[2], quad[3]] if j < nv - 1 else [])
+            if j == 0:
+                tris = ([quad[0], quad[2], quad[3]],)
+            elif j == nv - 1:
+                tris = ([quad[0], quad[1], quad[2]],)
+            for tri in tris:
+                if tri:
+                    lines.append("f " + " ".join("%d/%d/%d" % (vid(a, b), tid(a, b), vid(a, b)) for a, b in tri))
+    _write_if_changed(os.path.join(GENERATED, "obj_loader_test", "sphere.obj"), "\n".join(lines) + "\n")
+    cam = ("v -0.6 -0.4 0\nv 0.6 -0.4 0\nv 0.6 0.4 0\nv -0.6 0.4 0\n"
+           "v -0.6 -0.4 1.4\nv 0.6 -0.4 1.4\nv 0.6 0.4 1.4\nv -0.6 0.4 1.4\n"
+           "v 0 0 0\nv -0.5 -0.35 -0.8\nv 0.5 -0.35 -0.8\nv 0.5 0.35 -0.8\nv -0.5 0.35 -0.8\n"
+           "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+           "vn 0 0 -1\nvn 0 0 1\nvn -1 0 0\nvn 1 0 0\nvn 0 -1 0\nvn 0 1 0\n"
+           "f 1/1/1 4/4/1 3/3/1 2/2/1\nf 5/1/2 6/2/2 7/3/2 8/4/2\n"
+           "f 1/1/3 5/2/3 8/3/3 4/4/3\nf 2/1/4 3/4/4 7/3/4 6/2/4\n"
+           "f 1/1/5 2/2/5 6/3/5 5/4/5\nf 4/1/6 8/4/6 7/3/6 3/2/6\n"
+           "f 9/1/5 11/3/5 10/2/5\nf 9/1/4 12/3/4 11/2/4\nf 9/1/6 13/3/6 12/2/6\nf 9/1/3 10/3/3 13/2/3\n")
+    _write_if_changed(os.path.join(GENERATED, "obj_loader_test", "camera.obj"), cam)
+    return GENERATED
+
+
 # --------------------------------------------------------------------------- building blocks
 def _std_cameras(api, **over):
     kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
@@ -332,6 +378,27 @@ def cube_tetra_nodepth(api, resolution=(120, 160)):
     return _scene(api, cam, dbg, _std_light(api), resolution, [cube, tet, _floor(api)])
 
 
+def gizmos_small(api, resolution=(150, 200)):
+    """``show=True`` on the light and on the debug camera (obj/core.py:532-552): a sphere at the light's
+    place and a camera body at the debug camera's, both ``clip = False``, in front of the cube and the floor.
+    The scene is constructed from the directory that holds ``obj_loader_test/`` (upstream's relative paths)."""
+    here = os.getcwd()
+    os.chdir(gizmo_files())
+    try:
+        kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
+        cam = api.Camera((0.5, 1, 2), (0, 0, 0), **kw)
+        dbg = api.Camera((1.1, 0.5, 0.2), (0, 0, 0), show=True, **kw)
+        light = api.Light((-0.9, 1.0, 0.6), ambient_strength=0.1, specular_strength=0.1, show=True)
+        sc = api.Scene(cam, light, debug_camera=dbg, resolution=resolution)
+    finally:
+        os.chdir(here)
+    cube = api.Model.load_model(os.path.join(ASSETS, "cube", "cube.obj")) @ api.scale(0.5)
+    for m in (cube, _floor(api)):
+        sc.add_model(m)
+    sc.draw_debug_frustum = False
+    return sc
+
+
 def tetra_ortho(api, resolution=(120, 160)):
     """Orthographic camera (obj/transformation.py:139-154; only OpenGL + LH exists upstream):
     near = |position| (obj/core.py:389), float32 projection matrix."""
@@ -360,6 +427,7 @@ SMALL = {
     "kat_house": (kat_house, {}),
     "tetra_ortho": (tetra_ortho, {}),
     "cube_tetra_nodepth": (cube_tetra_nodepth, {}),
+    "gizmos_small": (gizmos_small, {}),
 }
 
 # BASELINE.json configs at full size: only the uint8 frame, winner map, stencil and z row sums are kept

@@ -101,10 +101,25 @@ def test_scene_api_surface(api):
     sc = scenes.cube_small(api)
     assert sc.resolution == (120, 160) and sc.camera.scene is sc and sc.debug_camera.scene is sc
     assert sc.camera.MVP is sc.camera.MVP                         # cached like the reference
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):                         # like upstream: the gizmo meshes are not shipped
         Scene(Camera((0, 0, 1), (0, 0, 0), show=True), Light((1, 1, 1)))
     assert Light((1, 2, 3)).light_type is Lightning.POINT_LIGHTNING
     assert Light((1, 1, 1), ambient_strength=0.1).ambient.tolist() == [0.1, 0.1, 0.1]
+
+
+def test_show_gizmos_follow_the_reference(api):
+    """``show=True`` (obj/core.py:532-552): the meshes are added in the order camera, light, debug camera,
+    before the caller's models, scaled by 0.1 and carried by the inverse look-at; ``clip`` off."""
+    sc = scenes.build(api, "gizmos_small")
+    sphere, body = sc.models[0], sc.models[1]
+    assert (len(sphere._faces), len(body._faces), len(sc.models)) == (100, 16, 4)
+    assert sphere.clip is False and body.clip is False and sphere.vertices.dtype == np.float64
+    centre = sphere.vertices[:, :3].mean(axis=0)
+    assert np.allclose(centre, sc.light.position, atol=1e-6)
+    assert np.allclose(np.linalg.norm(sphere.vertices[:, :3] - centre, axis=1), 0.1, atol=1e-6)
+    apex = body.vertices[8, :3]                                   # the lens' apex is the camera's position
+    assert np.allclose(apex, sc.debug_camera.position, atol=1e-6)
+    assert np.allclose(np.linalg.norm(sphere.normals, axis=1), 1.0, atol=1e-5)
 
 
 def _texture_digest(arr):
