@@ -121,11 +121,15 @@ __device__ __forceinline__ void bin_emit(const FrameConst &fc, const BinArgs &a,
 // out the returned range by rank, instead of queueing up to 64 deep on that location.  The
 // groups are found first (ALU only), then every group leader issues its atomic in the same
 // instruction: one memory round trip however many different bins the wavefront touches.
-__device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArgs &a, bool want, int cls,
-                                              uint32_t id, int tx, int ty)
+struct WaveEmit { unsigned long long mine; uint32_t base, tile; int leader, cls; };
+// first half: the groups and the leaders' atomics (the returned value is not looked at here, so several
+// of these can be in flight at once)
+__device__ __forceinline__ WaveEmit bin_emit_wave_issue(const FrameConst &fc, const BinArgs &a, bool want, int cls, int tx, int ty)
 {
-    const uint32_t tile = (uint32_t)ty * fc.tiles_x + tx;
-    const uint32_t bin = (uint32_t)cls * (uint32_t)(fc.tiles_x * fc.tiles_y) + tile;
+    WaveEmit w;
+    w.tile = (uint32_t)ty * fc.tiles_x + tx;
+    w.cls = cls;
+    const uint32_t bin = (uint32_t)cls * (uint32_t)(fc.tiles_x * fc.tiles_y) + w.tile;
     const int lane = threadIdx.x & (WAVE - 1);
     unsigned long long todo = __ballot(want), mine = 0;
     while (todo) {
@@ -136,11 +140,24 @@ __device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArg
         todo &= ~same;
     }
     if (!want) mine = 0;
-    const int my_leader = mine ? __ffsll((long long)mine) - 1 : lane;
-    uint32_t base = 0;
-    if (mine && lane == my_leader) base = atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mine));
-    base = (uint32_t)__shfl((int)base, my_leader);
-    if (mine) bin_store(a, cls, tile, base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull)), id);
+    w.mine = mine;
+    w.leader = mine ? __ffsll((long long)mine) - 1 : lane;
+    w.base = 0;
+    if (mine && lane == w.leader) w.base = atomicAdd(&a.bin_count[bin], (uint32_t)__popcll(mine));
+    return w;
+}
+// second half: the group shares out the range its leader got
+__device__ __forceinline__ void bin_emit_wave_store(const BinArgs &a, const WaveEmit &w, uint32_t id)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t base = (uint32_t)__shfl((int)w.base, w.leader);
+    if (w.mine) bin_store(a, w.cls, w.tile, base + (uint32_t)__popcll(w.mine & ((1ull << lane) - 1ull)), id);
+}
+__device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArgs &a, bool want, int cls,
+                                              uint32_t id, int tx, int ty)
+{
+    const WaveEmit w = bin_emit_wave_issue(fc, a, want, cls, tx, ty);
+    bin_emit_wave_store(a, w, id);
 }
 
 // A wavefront reserves work items for its lanes' large primitives with a single atomic (prefix
@@ -176,14 +193,24 @@ __device__ __forceinline__ void bin_triangles(const FrameConst &fc, const BinArg
     const int ntiles = valid ? (sp.tx1 - sp.tx0) * (sp.ty1 - sp.ty0) : 0;
     const bool small = valid && ntiles <= BIN_SMALL;
     if (__ballot(small)) {
+        // the (up to BIN_SMALL) cursors' atomics are all issued before the first returned value is used: a
+        // device-scope returning atomic takes ~2 us, and one after the other they were the longest stretch
+        // of a face's chain
         const int bw = max(sp.tx1 - sp.tx0, 1);
+        WaveEmit w[BIN_SMALL];
+        bool any[BIN_SMALL];
 #pragma unroll
         for (int slot = 0; slot < BIN_SMALL; ++slot) {
             const bool want = small && slot < ntiles;
-            if (!__ballot(want)) break;
-            const int tx = sp.tx0 + slot % bw, ty = sp.ty0 + slot / bw;
-            bin_emit_wave(fc, a, want, want ? pair_class(fc, false, clip, pb, tx, ty) : 0, face, tx, ty);
+            any[slot] = __ballot(want) != 0;
+            if (any[slot]) {
+                const int tx = sp.tx0 + slot % bw, ty = sp.ty0 + slot / bw;
+                w[slot] = bin_emit_wave_issue(fc, a, want, want ? pair_class(fc, false, clip, pb, tx, ty) : 0, tx, ty);
+            }
         }
+#pragma unroll
+        for (int slot = 0; slot < BIN_SMALL; ++slot)
+            if (any[slot]) bin_emit_wave_store(a, w[slot], face);
     }
     push_work_items(a, face, (valid && ntiles > BIN_SMALL) ? (uint32_t)(ntiles + WAVE - 1) / WAVE : 0u);
 }
@@ -232,10 +259,10 @@ __device__ __forceinline__ void bin_work_body(const FrameConst &fc, const BinArg
 // the set-up of the faces.  Wavefront w owns a contiguous quarter of the tiles and walks it 256 tiles at a
 // time (one 4-byte load per lane); counts and ranks come from ballots, so they are wavefront-uniform scalars
 // and the tiles of a class leave a wavefront for consecutive addresses.  Any tile of unknown class (0: a
-// first frame, a new grid) -> row-major order.  About 3 us for the 8160 tiles of a 1080p frame.
+// first frame, a new grid) -> row-major order.
 __device__ void order_tiles_block(const uint8_t *__restrict__ cls, uint32_t *__restrict__ order, int n_tiles)
 {
-    constexpr int NT = 256, NW = NT / WAVE, NC = ORDER_CLASSES + 1, STEP = 4 * WAVE, BATCH = 8;
+    constexpr int NT = 256, NW = NT / WAVE, NC = ORDER_CLASSES + 1, STEP = 4 * WAVE;
     __shared__ uint32_t s_wave[NC][NW];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
     const int quarter = (((n_tiles + NW - 1) / NW) + STEP - 1) / STEP * STEP;     // whole steps
@@ -248,19 +275,20 @@ __device__ void order_tiles_block(const uint8_t *__restrict__ cls, uint32_t *__r
         if (t < n_tiles && t + 4 > n_tiles) v |= 0xffffffffu << (8 * (n_tiles - t));
         return v;
     };
+    // (the step loops stay rolled: unrolled over a batch of steps the two walks were 50 KB of straight-line code,
+    // and fetching that cold took longer than executing it -- 15 us for the block instead of 4)
     uint32_t cnt[NC] = {};
-    for (int i0 = 0; i0 < steps; i0 += BATCH) {
-        uint32_t w[BATCH];
+    uint32_t next = steps > 0 ? fetch(0) : 0xffffffffu;
+#pragma unroll 1
+    for (int i = 0; i < steps; ++i) {
+        const uint32_t w = next;
+        next = i + 1 < steps ? fetch(i + 1) : 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) w[j] = i0 + j < steps ? fetch(i0 + j) : 0xffffffffu;
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t c = (w >> (8 * b)) & 0xffu;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t c = (w[j] >> (8 * b)) & 0xffu;
-#pragma unroll
-                for (int k = 0; k < NC; ++k) cnt[k] += (uint32_t)__popcll(__ballot(c == (uint32_t)k));
-            }
+            for (int k = 0; k < NC; ++k) cnt[k] += (uint32_t)__popcll(__ballot(c == (uint32_t)k));
+        }
     }
     if (lane == 0) {
 #pragma unroll
@@ -282,25 +310,24 @@ __device__ void order_tiles_block(const uint8_t *__restrict__ cls, uint32_t *__r
         base += all;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int i0 = 0; i0 < steps; i0 += BATCH) {
-        uint32_t w[BATCH];
+    next = steps > 0 ? fetch(0) : 0xffffffffu;
+#pragma unroll 1
+    for (int i = 0; i < steps; ++i) {
+        const uint32_t w = next;
+        next = i + 1 < steps ? fetch(i + 1) : 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) w[j] = i0 + j < steps ? fetch(i0 + j) : 0xffffffffu;
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t c = (w >> (8 * b)) & 0xffu;
+            const uint32_t t = (uint32_t)(w0 + i * STEP + 4 * lane + b);
+            uint32_t at = t;
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t c = (w[j] >> (8 * b)) & 0xffu;
-                const uint32_t t = (uint32_t)(w0 + (i0 + j) * STEP + 4 * lane + b);
-                uint32_t at = t;
-#pragma unroll
-                for (int k = 1; k < NC; ++k) {
-                    const unsigned long long m = __ballot(c == (uint32_t)k);
-                    if (c == (uint32_t)k) at = run[k] + (uint32_t)__popcll(m & below);
-                    run[k] += (uint32_t)__popcll(m);
-                }
-                if (c <= (uint32_t)ORDER_CLASSES) order[ORDER_HEAD + (known ? at : t)] = t;
+            for (int k = 1; k < NC; ++k) {
+                const unsigned long long m = __ballot(c == (uint32_t)k);
+                if (c == (uint32_t)k) at = run[k] + (uint32_t)__popcll(m & below);
+                run[k] += (uint32_t)__popcll(m);
             }
+            if (c <= (uint32_t)ORDER_CLASSES) order[ORDER_HEAD + (known ? at : t)] = t;
+        }
     }
 }
 

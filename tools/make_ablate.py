@@ -14,11 +14,36 @@ s = open(p).read()
 edits = [
     ("        for (uint32_t base = 0; base < n_big; base += WAVE) {",
      "        for (uint32_t base = 0; base < (MR_ABLATE == 4 ? 0u : n_big); base += WAVE) {"),
-    ("    if (n_small) {\n        s_key[lp]", "    if (n_small && MR_ABLATE != 3) {\n        s_key[lp]"),
+    ("    if (n_small) {\n        // ---- 2. small pairs", "    if (n_small && MR_ABLATE != 3) {\n        // ---- 2. small pairs"),
     ("    if (n_quad && (counters || __syncthreads_or(covered))) {",
      "    if (MR_ABLATE != 2 && n_quad && (counters || __syncthreads_or(covered))) {"),
     ("            shade_pixel(fc, t, at, *mp, px, py, lit, rgb);",
      "            if (MR_ABLATE == 1) rgb[0] = (float)at.dp[0] + (float)mp->ns + t.d00; else shade_pixel(fc, t, at, *mp, px, py, lit, rgb);"),
+]
+for a, b in edits:
+    assert s.count(a) == 1, a
+    s = s.replace(a, b)
+s = s.replace("namespace mr {\n", "#ifndef MR_ABLATE\n#define MR_ABLATE 0\n#endif\nnamespace mr {\n", 1)
+open(p, "w").write(s)
+# k_setup: 5 no attribute gather / store, 6 no survivor walk, 7 no tile lists, 8 no TriRec store either
+p = os.path.join(dst, "kernels_geometry.h")
+s = open(p).read()
+edits = [
+    ("    sa.attrs[f] = at;\n", "    if (MR_ABLATE != 5 && MR_ABLATE != 8 && MR_ABLATE != 19 && MR_ABLATE != 21) sa.attrs[f] = at;\n"),
+    ("    if (count_here) {\n        const int bw = bx1 - bx0;", "    if (count_here && MR_ABLATE != 6 && MR_ABLATE != 18) {\n        const int bw = bx1 - bx0;"),
+    ("    bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);", "    if (MR_ABLATE != 7 && MR_ABLATE != 20) bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);"),
+    ("    sa.tris[f] = t;\n", "    if (MR_ABLATE != 8 && MR_ABLATE != 21) sa.tris[f] = t;\n"),
+    ("        quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap,", "        if (MR_ABLATE != 9) quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap,"),
+    ("    if (b < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, b);", "    if (b < face_blocks) { if (MR_ABLATE != 10) tri_setup_block<PRE_XFORM>(fc, sa, bins, b); }"),
+    ("    else edge_block(fc, sa, bins, b - face_blocks);", "    else if (MR_ABLATE < 11) edge_block(fc, sa, bins, b - face_blocks);"),
+    # faces alone (no edge workgroups), cut short: 12 after the transform, 13 after the index row, 14 before the survivor walk
+    ("    uint8_t *status = sa.status;\n", "    uint8_t *status = sa.status;\n    if (MR_ABLATE == 12) { status[f] = (uint8_t)(A.sx + B.sy + C.sz > 1e300); return 0; }\n"),
+    ("    const double *wa = sa.verts + (size_t)ia.x * 4,", "    if (MR_ABLATE == 13) { sa.status[f] = (uint8_t)(ia.x + ib.y + ic.z + ff == -12345); return 0; }\n    const double *wa = sa.verts + (size_t)ia.x * 4,"),
+    ("    status[f] = FACE_OK;\n", "    status[f] = FACE_OK;\n    if (MR_ABLATE == 14) { status[f] = (uint8_t)(t.inv_den > 1e30f); return 0; }\n"),
+    # 12 and up: no tile-order sort either (15: the whole face path alone, 16: 15 without the workgroup epilogue, 17: the sort alone)
+    ("    if (blockIdx.x == 0) { order_tiles_block(", "    if (blockIdx.x == 0) { if (MR_ABLATE < 12 || MR_ABLATE == 17) order_tiles_block("),
+    ("    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);\n", "    if (MR_ABLATE == 16) return;\n    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);\n"),
+    ("    if (b < face_blocks) { if (MR_ABLATE != 10) tri", "    if (b < face_blocks) { if (MR_ABLATE != 10 && MR_ABLATE != 17) tri"),
 ]
 for a, b in edits:
     assert s.count(a) == 1, a
