@@ -145,8 +145,15 @@ def main():
     import scenes
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # MR_BENCH_REHEARSE=1: the N-rank path on ONE GPU (every rank on device 0, gloo instead of RCCL): checks the
+    # partition, the collective's layout and the assembled frame where no second GPU exists; its rates mean nothing
+    rehearse = world > 1 and os.environ.get("MR_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and rehearse:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene_name, label = CONFIGS[args.config]

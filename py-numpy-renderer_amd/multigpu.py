@@ -74,6 +74,13 @@ def all_gather_frame(part, frame=None, group=None):
         if frame.data_ptr() != part.data_ptr():
             frame.copy_(part)
         return frame
+    if part.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a machine without RCCL peers (several ranks sharing one GPU): gloo moves host memory
+        host = torch.empty(frame.shape, dtype=frame.dtype)
+        torch.cuda.current_stream().synchronize()
+        dist.all_gather_into_tensor(host.view(-1), part.contiguous().view(-1).cpu(), group=group)
+        frame.copy_(host)
+        return frame
     dist.all_gather_into_tensor(frame.view(-1), part.contiguous().view(-1), group=group)
     return frame
 
