@@ -124,6 +124,9 @@ class BandRenderer:
             gathered = torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda") if striped else frame
             self.lanes.append((stream, frame, part, gathered))
         self.index = unstripe_index(height, world, "cuda") if striped else None
+        # the collective's operands, flattened once (step() is the host's per-frame cost: keep it to the calls)
+        self._flat = [(g.view(-1), p.view(-1)) for _, _, p, g in self.lanes]
+        self._direct = world > 1 and dist.is_initialized() and dist.get_backend() != "gloo"
         self.desc = None
         self.descs, self.descs_untimed = [], []
         self.prime()
@@ -161,7 +164,11 @@ class BandRenderer:
         with torch.cuda.stream(stream):
             self.backend.enqueue(desc, part.data_ptr(), stream.cuda_stream)
             if self.world > 1:
-                all_gather_frame(part, gathered)
+                if self._direct:
+                    gflat, pflat = self._flat[(self.count - 1) % len(self.lanes)]
+                    dist.all_gather_into_tensor(gflat, pflat)
+                else:
+                    all_gather_frame(part, gathered)
                 if self.index is not None:
                     unstripe(gathered, self.height, self.world, out=frame, index=self.index)
         self.frame = frame
