@@ -166,6 +166,29 @@ def test_tile_row_stripes_tile_the_frame(api, name, world):
     scene.close()
 
 
+@pytest.mark.parametrize("name,world,rank", [("c4_torus200k_1080p", 8, 3), ("c3_diablo_floor_1080p", 8, 2)])
+def test_split_heavy_tiles_render_the_same_rows(api, name, world, rank):
+    """A device that owns few tiles (a rank of a multi-GPU split) shares the shadow quads of its heaviest tiles
+    out over four workgroups once the previous frame has told it which they are (kernels_tile.h HEAVY_SPLIT):
+    the first frame of a tile grid (row-major, one workgroup per tile) and the later ones (ordered, split)
+    must be the same rows, and some tile must actually qualify for the split."""
+    scene = scenes.build(api, name)
+    backend = scene._backend()
+    first = backend.render(scene, counters=False, stripe=(rank, world)).copy()
+    rec = backend.read_tile_records().astype(np.int64)
+    assert len(rec) <= 2048
+    cost = 30 + 3 * rec[:, 5] + 15 * rec[:, 6] + 6 * rec[:, 7]
+    heavy = (cost >= 600) & (rec[:, 7] >= 32)
+    assert heavy.any(), "no tile qualifies: the test would not exercise the split"
+    for _ in range(3):
+        again = backend.render(scene, counters=False, stripe=(rank, world))
+        order = backend.read_tile_order().astype(np.int64)
+        assert np.array_equal(np.sort(order), np.arange(len(rec)))
+        assert heavy[order[:int(heavy.sum())]].all()              # the qualifying tiles lead the order
+        assert np.array_equal(again, first)
+    scene.close()
+
+
 def test_work_lists_grow_on_overflow(api):
     """Per-tile lists start at a fixed capacity and grow when a tile overflows: with capacities forced
     far too small, mr_render (Scene.render) retries by itself and BandRenderer (frames enqueued without
