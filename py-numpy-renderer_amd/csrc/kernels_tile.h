@@ -49,9 +49,20 @@ __device__ __forceinline__ double z_unkey(unsigned long long k)
 // index.  Pairs that need the per-fragment clip test never come here (pair_class).
 constexpr int SMALL_LANES = 4;
 
+// What a lane's first sweep leaves for its second (see the winners' sweep in k_tile): the z keys and pixels
+// of its first SWEEP_CACHE_K samples that had a depth, and how many samples it walked in all.
+constexpr int SWEEP_CACHE_K = 2, SWEEP_CACHE_ROUNDS = 2;
+struct SweepCache {
+    unsigned long long key[SWEEP_CACHE_K];
+    uint32_t meta;                    // pixel of sample s in bits 8s..8s+7, "sample s is cached" in bit 16+s, samples walked from bit 20
+};
+
+// SWEEP 0 with `cache`: fills it.  SWEEP 1 with `first` > 0: skips the lane's first `first` samples (the cache
+// answered for them).
 template <int SWEEP>
 __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, int gx, int gy, bool rh,
-                                           unsigned long long *s_key, int *s_win, int sub, unsigned int &frags)
+                                           unsigned long long *s_key, int *s_win, int sub, unsigned int &frags,
+                                           SweepCache *cache = nullptr, int first = 0)
 {
     const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
     const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
@@ -60,30 +71,41 @@ __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t
     // The pixel then shows the LAST face in order among those that pass against the final z (see k_tile).
     const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
     const int bw = x1 - x0;
+    if (cache) { cache->meta = 0; }
     if (bw <= 0) return;
     int px = x0 + sub, py = y0;
     while (px >= x1) { px -= bw; ++py; }
+    int walked = 0;
     while (py < y1) {
-        float u, v, w;
-        tri_bary(t, (double)px, (double)py, single, u, v, w);
-        bool ok = u >= 0 && v >= 0 && w >= 0;
-        if (ok && SWEEP == 0) ++frags;
-        if (ok && (SWEEP == 1 || !nodepth)) {
-            const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
-                                       t.zl0, t.zl1, t.zl2);
-            if (z == z) {                            // a NaN depth never passes the reference's test
-                const int p = (py - gy) * TILE_W + (px - gx);
-                const unsigned long long k = z_key(z);
-                if (SWEEP == 0) {
-                    if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
-                } else if (nodepth ? (rh ? k <= s_key[p] : k >= s_key[p]) : s_key[p] == k) {
-                    atomicMax(&s_win[p], t.face);
+        if (SWEEP == 0 || walked >= first) {
+            float u, v, w;
+            tri_bary(t, (double)px, (double)py, single, u, v, w);
+            bool ok = u >= 0 && v >= 0 && w >= 0;
+            if (ok && SWEEP == 0) ++frags;
+            if (ok && (SWEEP == 1 || !nodepth)) {
+                const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
+                                           t.zl0, t.zl1, t.zl2);
+                if (z == z) {                            // a NaN depth never passes the reference's test
+                    const int p = (py - gy) * TILE_W + (px - gx);
+                    const unsigned long long k = z_key(z);
+                    if (SWEEP == 0) {
+                        if (rh) atomicMin(&s_key[p], k); else atomicMax(&s_key[p], k);
+                        if (cache) {
+#pragma unroll
+                            for (int c = 0; c < SWEEP_CACHE_K; ++c)
+                                if (walked == c) { cache->key[c] = k; cache->meta |= ((uint32_t)p << (8 * c)) | (1u << (16 + c)); }
+                        }
+                    } else if (nodepth ? (rh ? k <= s_key[p] : k >= s_key[p]) : s_key[p] == k) {
+                        atomicMax(&s_win[p], t.face);
+                    }
                 }
             }
         }
+        ++walked;
         px += SMALL_LANES;
         while (px >= x1) { px -= bw; ++py; }
     }
+    if (cache) cache->meta |= (uint32_t)walked << 20;
 }
 
 // Row of the device's output buffer that screen row py (in local tile row l) lands in.  A band of
@@ -319,10 +341,32 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
     if (n_small) {
         // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
+        // The second sweep (who owns the final z?) needs every sample's z key again.  For the first
+        // SWEEP_CACHE_ROUNDS rounds a lane leaves the keys of its first SWEEP_CACHE_K samples in LDS (the staging
+        // area of the shadow quads, not in use yet: 12 KB, exactly), with the face; the second sweep then
+        // compares those without the record, the barycentrics or the depth -- a mesh triangle of a few pixels is
+        // all cache.  Lanes with more samples, later rounds and faces that do not write z walk again.
+        unsigned long long (*c_key)[SWEEP_CACHE_K][TILE_PX] =
+            reinterpret_cast<unsigned long long (*)[SWEEP_CACHE_K][TILE_PX]>(s_quad);
+        uint32_t (*c_meta)[TILE_PX] = reinterpret_cast<uint32_t (*)[TILE_PX]>(
+            reinterpret_cast<unsigned long long *>(s_quad) + SWEEP_CACHE_ROUNDS * SWEEP_CACHE_K * TILE_PX);
+        uint32_t (*c_face)[TILE_PX] = c_meta + SWEEP_CACHE_ROUNDS;
+        static_assert(SWEEP_CACHE_ROUNDS * TILE_PX * (SWEEP_CACHE_K * 8 + 8) <= (int)sizeof(s_quad), "sweep cache fits the quad area");
         unsigned int sfrags = 0;
-        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
+        int round = 0;
+        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES, ++round) {
             const TriRec t = tris[small_items[i]];
-            small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+            if (round < SWEEP_CACHE_ROUNDS) {
+                SweepCache sc;
+                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags, &sc);
+                const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
+#pragma unroll
+                for (int c = 0; c < SWEEP_CACHE_K; ++c) c_key[round][c][tid] = sc.key[c];
+                c_meta[round][tid] = nodepth ? (sc.meta & 0xfff00000u) : sc.meta;      // nothing cached for a face that writes no z
+                c_face[round][tid] = (uint32_t)t.face | (nodepth ? 0x80000000u : 0u);
+            } else {
+                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+            }
         }
         if (sfrags) atomicAdd(&s_cnt[0], sfrags);
         __syncthreads();
@@ -331,9 +375,24 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         // largest face index among those at the final z, in any order)
         const unsigned long long kfinal = s_key[lp];
         if (best >= 0 && kfinal == z_key(zbest)) atomicMax(&s_win[lp], best);
-        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES) {
+        round = 0;
+        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES, ++round) {
+            int first = 0;
+            if (round < SWEEP_CACHE_ROUNDS) {
+                const uint32_t meta = c_meta[round][tid], cf = c_face[round][tid];
+                const int walked = (int)(meta >> 20);
+                const bool nodepth = (cf >> 31) != 0;
+#pragma unroll
+                for (int c = 0; c < SWEEP_CACHE_K; ++c)
+                    if ((meta >> (16 + c)) & 1u) {
+                        const int p = (int)((meta >> (8 * c)) & 0xffu);
+                        if (s_key[p] == c_key[round][c][tid]) atomicMax(&s_win[p], (int)(cf & 0x7fffffffu));
+                    }
+                if (!nodepth && walked <= SWEEP_CACHE_K) continue;     // the cache answered for every sample of this lane
+                first = nodepth ? 0 : SWEEP_CACHE_K;
+            }
             const TriRec t = tris[small_items[i]];
-            small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+            small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags, nullptr, first);
         }
         __syncthreads();
         best = s_win[lp];

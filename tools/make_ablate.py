@@ -12,6 +12,11 @@ for name in os.listdir(dst):
 p = os.path.join(dst, "kernels_tile.h")
 s = open(p).read()
 edits = [
+    # 30: extra time stamps in the (then unused) counter words of the tile record: [0] lists known, [1] big pairs done,
+    #     [2] first sweep done, [3] shading's records loaded
+    ("    big_pairs(false);\n", "    const unsigned long long t_lists = __builtin_amdgcn_s_memrealtime();\n    big_pairs(false);\n    const unsigned long long t_big = __builtin_amdgcn_s_memrealtime();\n    unsigned long long t_sweep0 = t_big;\n"),
+    ("        if (sfrags) atomicAdd(&s_cnt[0], sfrags);\n        __syncthreads();\n", "        if (sfrags) atomicAdd(&s_cnt[0], sfrags);\n        __syncthreads();\n        t_sweep0 = __builtin_amdgcn_s_memrealtime();\n"),
+    ("    if (tid < TILE_STATS) rec[tid] = s_cnt[tid];\n", "    if (tid < TILE_STATS) rec[tid] = s_cnt[tid];\n    if (MR_ABLATE == 30 && tid == 0) { rec[0] = (uint32_t)t_lists; rec[1] = (uint32_t)t_big; rec[2] = (uint32_t)t_sweep0; }\n"),
     ("        for (uint32_t base = 0; base < n_big; base += WAVE) {",
      "        for (uint32_t base = 0; base < (MR_ABLATE == 4 ? 0u : n_big); base += WAVE) {"),
     ("    if (n_small) {\n        // ---- 2. small pairs", "    if (n_small && MR_ABLATE != 3) {\n        // ---- 2. small pairs"),
@@ -35,13 +40,13 @@ edits = [
     ("    sa.tris[f] = t;\n", "    if (MR_ABLATE != 8 && MR_ABLATE != 21) sa.tris[f] = t;\n"),
     ("        quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap,", "        if (MR_ABLATE != 9) quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap,"),
     ("    if (b < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, b);", "    if (b < face_blocks) { if (MR_ABLATE != 10) tri_setup_block<PRE_XFORM>(fc, sa, bins, b); }"),
-    ("    else edge_block(fc, sa, bins, b - face_blocks);", "    else if (MR_ABLATE < 11) edge_block(fc, sa, bins, b - face_blocks);"),
+    ("    else edge_block(fc, sa, bins, b - face_blocks);", "    else if (MR_ABLATE < 11 || MR_ABLATE > 21) edge_block(fc, sa, bins, b - face_blocks);"),
     # faces alone (no edge workgroups), cut short: 12 after the transform, 13 after the index row, 14 before the survivor walk
     ("    uint8_t *status = sa.status;\n", "    uint8_t *status = sa.status;\n    if (MR_ABLATE == 12) { status[f] = (uint8_t)(A.sx + B.sy + C.sz > 1e300); return 0; }\n"),
     ("    const double *wa = sa.verts + (size_t)ia.x * 4,", "    if (MR_ABLATE == 13) { sa.status[f] = (uint8_t)(ia.x + ib.y + ic.z + ff == -12345); return 0; }\n    const double *wa = sa.verts + (size_t)ia.x * 4,"),
     ("    status[f] = FACE_OK;\n", "    status[f] = FACE_OK;\n    if (MR_ABLATE == 14) { status[f] = (uint8_t)(t.inv_den > 1e30f); return 0; }\n"),
     # 12 and up: no tile-order sort either (15: the whole face path alone, 16: 15 without the workgroup epilogue, 17: the sort alone)
-    ("    if (blockIdx.x == 0) { order_tiles_block(", "    if (blockIdx.x == 0) { if (MR_ABLATE < 12 || MR_ABLATE == 17) order_tiles_block("),
+    ("    if (blockIdx.x == 0) { order_tiles_block(", "    if (blockIdx.x == 0) { if (MR_ABLATE < 12 || MR_ABLATE == 17 || MR_ABLATE > 21) order_tiles_block("),
     ("    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);\n", "    if (MR_ABLATE == 16) return;\n    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);\n"),
     ("    if (b < face_blocks) { if (MR_ABLATE != 10) tri", "    if (b < face_blocks) { if (MR_ABLATE != 10 && MR_ABLATE != 17) tri"),
 ]
