@@ -19,9 +19,10 @@ edits = [
     ("    if (tid < TILE_STATS) rec[tid] = s_cnt[tid];\n", "    if (tid < TILE_STATS) rec[tid] = s_cnt[tid];\n    if (MR_ABLATE == 30 && tid == 0) { rec[0] = (uint32_t)t_lists; rec[1] = (uint32_t)t_big; rec[2] = (uint32_t)t_sweep0; }\n"),
     ("        for (uint32_t base = 0; base < n_big; base += WAVE) {",
      "        for (uint32_t base = 0; base < (MR_ABLATE == 4 ? 0u : n_big); base += WAVE) {"),
-    ("    if (n_small) {\n        // ---- 2. small pairs", "    if (n_small && MR_ABLATE != 3) {\n        // ---- 2. small pairs"),
+    ("    if (n_small) {\n        // ---- 2. small pairs", "    if (n_small && MR_ABLATE != 3 && MR_ABLATE != 31) {\n        // ---- 2. small pairs"),
+    ("__global__ void __launch_bounds__(TILE_PX, 5)\nk_tile(", "#ifndef MR_TILE_OCC\n#define MR_TILE_OCC 5\n#endif\n__global__ void __launch_bounds__(TILE_PX, MR_TILE_OCC)\nk_tile("),
     ("    if (n_quad && (counters || __syncthreads_or(covered))) {",
-     "    if (MR_ABLATE != 2 && n_quad && (counters || __syncthreads_or(covered))) {"),
+     "    if (MR_ABLATE != 2 && MR_ABLATE != 31 && n_quad && (counters || __syncthreads_or(covered))) {"),
     ("            shade_pixel(fc, t, at, *mp, px, py, lit, rgb);",
      "            if (MR_ABLATE == 1) rgb[0] = (float)at.dp[0] + (float)mp->ns + t.d00; else shade_pixel(fc, t, at, *mp, px, py, lit, rgb);"),
 ]
