@@ -20,6 +20,8 @@ edits = [
     ("        for (uint32_t base = 0; base < n_big; base += WAVE) {",
      "        for (uint32_t base = 0; base < (MR_ABLATE == 4 ? 0u : n_big); base += WAVE) {"),
     ("    if (n_small) {\n        // ---- 2. small pairs", "    if (n_small && MR_ABLATE != 3 && MR_ABLATE != 31) {\n        // ---- 2. small pairs"),
+    # MR_TILE_PAD_KB: LDS ballast, to hold fewer workgroups on a CU (how does the launch time follow occupancy?)
+    ("    __shared__ float s_gamma[GAMMA_LUT_SIZE];\n", "    __shared__ float s_gamma[GAMMA_LUT_SIZE];\n#ifdef MR_TILE_PAD_KB\n    __shared__ uint32_t s_pad[MR_TILE_PAD_KB * 256];\n    if (fc.width < 0) { s_pad[threadIdx.x] = (uint32_t)fc.height; __syncthreads(); if (s_pad[threadIdx.x ^ 1] == 77u) return; }\n#endif\n"),
     ("__global__ void __launch_bounds__(TILE_PX, 5)\nk_tile(", "#ifndef MR_TILE_OCC\n#define MR_TILE_OCC 5\n#endif\n__global__ void __launch_bounds__(TILE_PX, MR_TILE_OCC)\nk_tile("),
     ("    if (n_quad && (counters || __syncthreads_or(covered))) {",
      "    if (MR_ABLATE != 2 && MR_ABLATE != 31 && n_quad && (counters || __syncthreads_or(covered))) {"),
