@@ -251,12 +251,24 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     const uint32_t *__restrict__ quad_items = ta.items[2] + (size_t)tile * ta.cap[2];
 
     // Nothing listed for this tile (a third of a typical frame): its pixels show the background, which
-    // the host has finalised already.  Shadow quads over it only matter to the counters.
-    if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (fc.background_u8 >> 24) &&
-        !((fc.flags & MR_FRAME_SKYBOX) && sh.sky) && !sh.frame && !ta.zbuf) {
+    // the host has finalised already, or the skybox (no lists to walk, no barriers but the gamma table's).
+    // Shadow quads over it only matter to the counters.
+    const bool sky_tile = (fc.flags & MR_FRAME_SKYBOX) && sh.sky;
+    if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (sky_tile || (fc.background_u8 >> 24)) &&
+        !sh.frame && !ta.zbuf) {
         if (part != 0) return;                            // (a tile that was heavy a frame ago: one part will do)
-        if (live) {
-            uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
+        uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
+        if (sky_tile) {
+            s_gamma[tid] = sh.gamma_lut[tid];
+            if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
+            float rgb[3] = { 0.f, 0.f, 0.f };
+            if (live) sky_color(fc, sh.sky, px, py, rgb);
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
+            }
+        } else if (live) {
             o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
         }
         if (tid == 0) {
