@@ -61,7 +61,7 @@ struct SweepCache {
 // answered for them).
 template <int SWEEP>
 __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, int gx, int gy, bool rh,
-                                           unsigned long long *s_key, int *s_win, int sub, unsigned int &frags,
+                                           unsigned long long *s_key, int *s_win, int sub, int lanes, unsigned int &frags,
                                            SweepCache *cache = nullptr, int first = 0)
 {
     const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
@@ -102,7 +102,7 @@ __device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t
             }
         }
         ++walked;
-        px += SMALL_LANES;
+        px += lanes;
         while (px >= x1) { px -= bw; ++py; }
     }
     if (cache) cache->meta |= (uint32_t)walked << 20;
@@ -366,18 +366,23 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         static_assert(SWEEP_CACHE_ROUNDS * TILE_PX * (SWEEP_CACHE_K * 8 + 8) <= (int)sizeof(s_quad), "sweep cache fits the quad area");
         unsigned int sfrags = 0;
         int round = 0;
-        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES, ++round) {
+        // SMALL_LANES lanes per pair; two where the list is longer than one round of those (a round is two
+        // dependent memory round trips whatever it holds: 65 pairs in two rounds cost twice what 64 do)
+        const int spl = n_small > (uint32_t)(TILE_PX / SMALL_LANES) ? SMALL_LANES / 2 : SMALL_LANES;
+        const uint32_t per_round = (uint32_t)(TILE_PX / spl), my_pair = (uint32_t)(tid / spl);
+        const int sub = tid % spl;
+        for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
             const TriRec t = tris[small_items[i]];
             if (round < SWEEP_CACHE_ROUNDS) {
                 SweepCache sc;
-                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags, &sc);
+                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags, &sc);
                 const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
 #pragma unroll
                 for (int c = 0; c < SWEEP_CACHE_K; ++c) c_key[round][c][tid] = sc.key[c];
                 c_meta[round][tid] = nodepth ? (sc.meta & 0xfff00000u) : sc.meta;      // nothing cached for a face that writes no z
                 c_face[round][tid] = (uint32_t)t.face | (nodepth ? 0x80000000u : 0u);
             } else {
-                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags);
+                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags);
             }
         }
         if (sfrags) atomicAdd(&s_cnt[0], sfrags);
@@ -388,7 +393,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         const unsigned long long kfinal = s_key[lp];
         if (best >= 0 && kfinal == z_key(zbest)) atomicMax(&s_win[lp], best);
         round = 0;
-        for (uint32_t i = tid / SMALL_LANES; i < n_small; i += TILE_PX / SMALL_LANES, ++round) {
+        for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
             int first = 0;
             if (round < SWEEP_CACHE_ROUNDS) {
                 const uint32_t meta = c_meta[round][tid], cf = c_face[round][tid];
@@ -404,7 +409,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                 first = nodepth ? 0 : SWEEP_CACHE_K;
             }
             const TriRec t = tris[small_items[i]];
-            small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, tid % SMALL_LANES, sfrags, nullptr, first);
+            small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags, nullptr, first);
         }
         __syncthreads();
         best = s_win[lp];
