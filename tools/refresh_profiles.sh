@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: everything under profiles/<round>_* that depends on the kernels, in one go (about 4 GPU-minutes).
 # Results land in gpurun_out/refresh/ under their profiles/ names; copy them over afterwards:
-#   gpurun -- 'bash tools/refresh_profiles.sh r02' && cp gpurun_out/refresh/r02_* profiles/ && python tools/make_traffic_json.py r02 c4 c5
+#   gpurun -- 'bash tools/refresh_profiles.sh r02' && cp gpurun_out/refresh/r02_* profiles/ && python tools/make_traffic_json.py r02 c2 c3 c4 c5
 rnd=${1:-r02}
 R=$GRAFT_REPO_ROOT/gpurun_out/refresh; rm -rf $R; mkdir -p $R
 cd $GRAFT_REPO_ROOT
@@ -16,6 +16,8 @@ done
 # HBM traffic per kernel (two --pmc passes each)
 bash tools/prof_traffic.sh c4_torus200k_1080p c4 > $R/${rnd}_c4_pmc_fetch_write.txt 2>&1 || exit 1
 bash tools/prof_traffic.sh c5_torus1m_4k_skybox c5 > $R/${rnd}_c5_pmc_fetch_write.txt 2>&1 || exit 1
+bash tools/prof_traffic.sh c2_diablo_1080p c2 > $R/${rnd}_c2_pmc_fetch_write.txt 2>&1 || exit 1
+bash tools/prof_traffic.sh c3_diablo_floor_1080p c3 > $R/${rnd}_c3_pmc_fetch_write.txt 2>&1 || exit 1
 # SQ counters of the frame's kernels on c4 (two passes: the counters do not fit one)
 { bash tools/prof_pmc.sh sq1 k_ SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY
   bash tools/prof_pmc.sh sq2 k_ SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_F64; } > $R/${rnd}_c4_pmc_sq_counters.txt 2>&1 || exit 1

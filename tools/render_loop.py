@@ -11,5 +11,5 @@ sc = scenes.build(api, name)
 be = sc._backend()
 counters = not (len(sys.argv) > 3 and sys.argv[3] == "frame-only")
 for _ in range(n):
-    be.render(sc, shadows=True, counters=counters)
+    be.render(sc, shadows=name not in scenes.NO_SHADOW, counters=counters)
 print(be.last_stats)
