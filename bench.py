@@ -13,8 +13,9 @@ the diablo configs.
 A frame is the whole hot path: per-frame constants in, vertex transform, face set-up, silhouette
 + shadow-quad set-up, binning, tile visibility (coverage, z, stencil), deferred shading and
 finalise to uint8, with the scene already resident in HBM and the frame left in HBM
-(``mr_render_device``).  A STEP is a batch of ``--frames-per-step`` (default 256) frames, so that the
-timed region is about half a second whatever --steps is; successive frames use DIFFERENT per-frame
+(``mr_render_device``).  A STEP is a batch of frames -- at least ``--frames-per-step`` (default 256), and as
+many as it takes for the K timed steps to last 0.6 s at the rate of a short calibration run (``frames_per_step``
+in the line says how many) -- so the timed region does not depend on --steps; successive frames use DIFFERENT per-frame
 constants (the camera swings through 8 slightly different views), and ``--frames-in-flight``
 (default 3) of them are in flight on separate HIP streams.  With N > 1 every rank renders its share
 of the screen tiles (interleaved tile rows by default, ``--partition bands`` for contiguous row
@@ -225,6 +226,18 @@ def main():
     if not br.verify():                  # a work list overflowed during warm-up: it has been grown, warm up again
         run(br, args.warmup * fps)
         assert br.verify(), "work lists kept overflowing"
+    # A step is a batch of frames, sized so that the K timed steps last at least ~0.6 s whatever the config and
+    # however fast a frame has become (the default 256 did that for c4 until a frame dropped under 0.1 ms): the
+    # rate of a short calibration run (untimed as far as the result goes) decides, the same on every rank.
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(br, 256)
+    torch.cuda.synchronize()
+    est = torch.tensor([(time.perf_counter() - t0) / 256], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    need = int(0.6 / (max(args.steps, 1) * max(float(est.item()), 1e-6))) + 1
+    fps = max(fps, -(-need // 8) * 8)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
