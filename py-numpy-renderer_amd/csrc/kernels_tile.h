@@ -12,9 +12,9 @@
 //   1. big (triangle, tile) pairs -- a floor triangle -- one PIXEL per thread, the records staged
 //      64 at a time in LDS and read as broadcasts (obj/triangular.py:72-118);
 //   2. small pairs -- a dense mesh's triangles cover a handful of samples -- four lanes per
-//      TRIANGLE: they share out the few samples of the pixel box and do an LDS atomicMin on the
-//      order-preserving key of z, then (second sweep) an LDS atomicMax of the face index where its
-//      z is the tile's final z.  The reference's sequential rule (a fragment writes when
+//      TRIANGLE (two where the tile lists more than a round of those): they share out the few samples of
+//      the pixel box and do an LDS atomicMin on the order-preserving key of z, then (second sweep, from
+//      the keys the first left in LDS) an LDS atomicMax of the face index where its z is the tile's final z.  The reference's sequential rule (a fragment writes when
 //      zbuf >= z, so the last face in order wins ties) is reproduced order-free: smallest z, and
 //      among equal z the largest face index;
 //   3. the tile's shadow quads against the final z, QUAD_BATCH records staged in LDS per round,
