@@ -12,6 +12,8 @@ for name in os.listdir(dst):
 p = os.path.join(dst, "kernels_tile.h")
 s = open(p).read()
 edits = [
+    # 40 / 41: one / two EXTRA dependent scalar loads at the head of every listed tile's chain (what is a round trip worth?)
+    ("    if (tid < TILE_STATS) s_cnt[tid] = 0;\n    s_gamma[tid] = sh.gamma_lut[tid];\n", "    if (MR_ABLATE == 40 || MR_ABLATE == 41) {\n        uint32_t x = ta.bin_count[(uint32_t)(tile * 7 + 1) % (uint32_t)(3 * n_tiles)];\n        if (MR_ABLATE == 41) x = ta.bin_count[(x + (uint32_t)tile * 13u) % (uint32_t)(3 * n_tiles)];\n        if (x == 0xdeadbeefu) return;\n    }\n    if (tid < TILE_STATS) s_cnt[tid] = 0;\n    s_gamma[tid] = sh.gamma_lut[tid];\n"),
     # 30: extra time stamps in the (then unused) counter words of the tile record: [0] lists known, [1] big pairs done,
     #     [2] first sweep done, [3] shading's records loaded
     ("    big_pairs(false);\n", "    const unsigned long long t_lists = __builtin_amdgcn_s_memrealtime();\n    big_pairs(false);\n    const unsigned long long t_big = __builtin_amdgcn_s_memrealtime();\n    unsigned long long t_sweep0 = t_big;\n"),
