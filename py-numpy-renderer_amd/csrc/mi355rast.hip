@@ -103,6 +103,7 @@ struct FrameSlot {
 
     mr_frame_desc last_frame = {};
     int last_n_tiles = 0;
+    bool last_ordered = false;               // the last frame's tile kernel followed the order buffer (else row-major)
     bool have_frame = false, stats_reduced = false;
 
     void reset_caps() { bins_zeroed_for = 0; have_frame = false; }
@@ -563,6 +564,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     fs->last_serial = sc->frame_serial;
     const bool ordered = order_mode == 2 || (order_mode == 0 && alone);
     ta.order = ordered ? order : nullptr; ta.tile_class = tile_class;
+    fs->last_ordered = ordered;
     // a device whose tiles all fit on the chip at once (a rank of a multi-GPU split) shares out the quads of
     // its heaviest tiles: there the launch lasts as long as the slowest tile (see HEAVY_SPLIT)
     ta.split_arrive = fs->d_split.as<uint32_t>();
@@ -1136,8 +1138,10 @@ int mr_debug_read_tile_order(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
     if (!out) return fail(MR_E_INVALID, "NULL argument");
     const int n = std::min(fs->last_n_tiles, cap_tiles);
     HIP_TRY(hipDeviceSynchronize());
-    if (n > 0)
+    if (n > 0 && fs->last_ordered)
         HIP_TRY(hipMemcpy(out, fs->d_hist.as<uint32_t>() + mr::ORDER_HEAD, (size_t)n * 4, hipMemcpyDeviceToHost));
+    else
+        for (int i = 0; i < n; ++i) out[i] = (uint32_t)i;     // frames rendered from several streams keep row-major order
     return fs->last_n_tiles;
 }
 

@@ -134,6 +134,22 @@ def test_heaviest_first_tile_order_is_a_permutation(api, name, shadows):
     scene.close()
 
 
+def test_frames_from_several_streams_keep_row_major_order(api):
+    """The tile order is for a frame that has the device to itself; a scene rendered from several streams at
+    once (frames in flight) keeps row-major order (mi355rast.hip, enqueue_frame) -- and the same frames."""
+    from py_numpy_renderer_amd.multigpu import BandRenderer
+    scene = scenes.build(api, "diablo_floor_small")
+    want = scene.render()
+    br = BandRenderer(scene, frames_in_flight=3, timing_every=0)
+    for _ in range(9):
+        frame = br.step()
+    assert br.verify()
+    order = scene._backend().read_tile_order()
+    assert np.array_equal(order, np.arange(len(order), dtype=np.uint32))
+    assert np.array_equal(frame.cpu().numpy(), want)
+    scene.close()
+
+
 @pytest.mark.parametrize("bands", [2, 3, 8])
 def test_row_bands_tile_the_frame(api, bands):
     """Screen-tile split: rendering disjoint row bands and stacking them gives the whole frame
