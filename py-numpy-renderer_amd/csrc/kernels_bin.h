@@ -162,10 +162,16 @@ __device__ __forceinline__ void bin_emit_wave(const FrameConst &fc, const BinArg
 
 // A wavefront reserves work items for its lanes' large primitives with a single atomic (prefix
 // sum of the lanes' chunk counts), then every lane writes its own.  Every lane must call it.
-__device__ __forceinline__ void push_work_items(const BinArgs &a, uint32_t prim, uint32_t chunks)
+constexpr uint32_t WORK_NONE = 0xffffffffu;     // a reserved work item nobody needs after all (k_bin_work skips it)
+
+// first half: the wavefront's reservation (one atomic; its result is not looked at here, so other requests can
+// be in flight beside it).  Every lane must call it; returns false when no lane has anything.
+struct WorkSlot { uint32_t base_raw, offset; };
+__device__ __forceinline__ bool reserve_work_items(const BinArgs &a, uint32_t chunks, WorkSlot &w)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    if (!__ballot(chunks != 0)) return;
+    w.base_raw = 0; w.offset = 0;
+    if (!__ballot(chunks != 0)) return false;
     uint32_t incl = chunks;
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) {
@@ -173,13 +179,23 @@ __device__ __forceinline__ void push_work_items(const BinArgs &a, uint32_t prim,
         if (lane >= off) incl += y;
     }
     const uint32_t wave_total = __shfl(incl, WAVE - 1);
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&a.ctr->n_work, wave_total);
-    base = __shfl(base, 0) + incl - chunks;
+    if (lane == 0) w.base_raw = atomicAdd(&a.ctr->n_work, wave_total);
+    w.offset = incl - chunks;
+    return true;
+}
+// second half: every lane writes its own items
+__device__ __forceinline__ void fill_work_items(const BinArgs &a, const WorkSlot &w, uint32_t prim, uint32_t chunks)
+{
+    const uint32_t base = __shfl(w.base_raw, 0) + w.offset;
     for (uint32_t c = 0; c < chunks; ++c) {
         if (base + c < a.work_cap) a.work[base + c] = make_uint2(prim, c);
         else atomicOr(&a.ctr->overflow, 8u);
     }
+}
+__device__ __forceinline__ void push_work_items(const BinArgs &a, uint32_t prim, uint32_t chunks)
+{
+    WorkSlot w;
+    if (reserve_work_items(a, chunks, w)) fill_work_items(a, w, prim, chunks);
 }
 
 // One lane per triangle (valid: the lane has one; face, pixel box and TF_CLIP given).  Small
@@ -231,6 +247,7 @@ __device__ __forceinline__ void bin_work_body(const FrameConst &fc, const BinArg
     const uint32_t waves = n_blocks * (blockDim.x / WAVE);
     for (uint32_t w = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; w < n_work; w += waves) {
         const uint2 item = a.work[w];
+        if (item.x == WORK_NONE) continue;
         const bool is_quad = (item.x & WORK_QUAD) != 0;
         const uint32_t id = item.x & ~WORK_QUAD;
         PrimBox pb;

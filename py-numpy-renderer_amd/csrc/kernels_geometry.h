@@ -559,7 +559,7 @@ constexpr int QS_LANES = 16;
 static_assert(MAX_POLY <= QS_LANES, "one polygon vertex per lane");
 
 __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins,
-                                                 bool have, int sil_f, int sil_k, uint32_t s_idx,
+                                                 bool have, int sil_f, int sil_k, uint32_t s_base_raw, uint32_t s_rank,
                                                  double (*s_poly)[MAX_POLY + 4][4])
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -672,15 +672,19 @@ __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const Set
     double xs[2] = { lo_x, hi_x }, ys[2] = { lo_y, hi_y };
     int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
     const bool boxed = alive && bound_box(xs, ys, 2, fc.width, fc.height, bx0, bx1, by0, by1);
+    // the quad's record slot and its work items of 64 tiles (kernels_bin.h; all lanes take part): two returning
+    // atomics, ~2 us each, both requested before either answer is used
     uint32_t slot = 0;
     if (boxed && gl == 0) slot = atomicAdd(&sa.ctr->n_quads_drawn, 1u);
+    const uint32_t chunks = (boxed && gl == 0) ? quad_chunks(fc, bx0, bx1, by0, by1) : 0u;
+    WorkSlot ws;
+    const bool any_work = reserve_work_items(bins, chunks, ws);
     slot = (uint32_t)__shfl((int)slot, g0);
-    // the quad as work items of 64 tiles (kernels_bin.h); all lanes take part
-    push_work_items(bins, WORK_QUAD | slot,
-                    (boxed && gl == 0 && slot < sa.quad_cap) ? quad_chunks(fc, bx0, bx1, by0, by1) : 0u);
+    if (any_work) fill_work_items(bins, ws, slot < sa.quad_cap ? (WORK_QUAD | slot) : WORK_NONE, chunks);
     if (!boxed) return;
     if (slot >= sa.quad_cap) { if (gl == 0) atomicOr(&sa.ctr->overflow, 16u); return; }
 
+    const uint32_t s_idx = (uint32_t)__shfl((int)s_base_raw, 0) + s_rank;
     QuadRec &q = sa.quads[slot];
     if (gl < MAX_POLY) {
         QuadEdge e;
@@ -697,7 +701,7 @@ __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const Set
         q.d = chain3(-x0, -y0, -z0, nx, ny, nz);
         q.is_front = nz < 0;
         q.n = n;
-        q.edge = (int32_t)s_idx;
+        q.edge = (int32_t)s_idx;                  // (the silhouette list's atomic has had the whole set-up to come back)
         q.x0 = (int16_t)bx0; q.x1 = (int16_t)bx1; q.y0 = (int16_t)by0; q.y1 = (int16_t)by1;
         q.pad[0] = q.pad[1] = q.pad[2] = 0;
     }
@@ -748,15 +752,11 @@ __device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs
     }
     unsigned long long todo = __ballot(sil);
     if (!todo) return;
-    // the wavefront's silhouette edges get consecutive list slots with one atomic
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&sa.ctr->n_quads, (uint32_t)__popcll(todo));
-    base = (uint32_t)__shfl((int)base, 0);
-    const uint32_t my_slot = base + (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
-    if (sil && my_slot < sa.quad_cap) {
-        sa.sil_edges[my_slot * 2 + 0] = (int32_t)(last >> 2);       // the host maps the face back to its model
-        sa.sil_edges[my_slot * 2 + 1] = (int32_t)(last & 3u);
-    }
+    // the wavefront's silhouette edges get consecutive list slots with one atomic; its answer is first needed
+    // at the end of the quad set-up (the records' back references), so it is not waited for here
+    uint32_t base_raw = 0;
+    if (lane == 0) base_raw = atomicAdd(&sa.ctr->n_quads, (uint32_t)__popcll(todo));
+    const uint32_t my_rank = (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
     // quad set-up, four silhouette edges per round (one per 16-lane group)
     const int grp = lane / QS_LANES;
     while (todo) {
@@ -770,8 +770,13 @@ __device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs
         for (int g = 0; g < WAVE / QS_LANES && todo; ++g) todo &= todo - 1;
         const bool have = src >= 0;
         const uint32_t ls = (uint32_t)__shfl((int)last, have ? src : 0);
-        const uint32_t slot = (uint32_t)__shfl((int)my_slot, have ? src : 0);
-        quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap, (int)(ls >> 2), (int)(ls & 3u), slot, s_poly[wv]);
+        const uint32_t rank = (uint32_t)__shfl((int)my_rank, have ? src : 0);
+        quad_setup_group(fc, sa, bins, have, (int)(ls >> 2), (int)(ls & 3u), base_raw, rank, s_poly[wv]);
+    }
+    const uint32_t my_slot = (uint32_t)__shfl((int)base_raw, 0) + my_rank;
+    if (sil && my_slot < sa.quad_cap) {
+        sa.sil_edges[my_slot * 2 + 0] = (int32_t)(last >> 2);       // the host maps the face back to its model
+        sa.sil_edges[my_slot * 2 + 1] = (int32_t)(last & 3u);
     }
 }
 

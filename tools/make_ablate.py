@@ -43,17 +43,21 @@ edits = [
     ("    if (count_here) {\n        const int bw = bx1 - bx0;", "    if (count_here && MR_ABLATE != 6 && MR_ABLATE != 18) {\n        const int bw = bx1 - bx0;"),
     ("    bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);", "    if (MR_ABLATE != 7 && MR_ABLATE != 20) bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);"),
     ("    sa.tris[f] = t;\n", "    if (MR_ABLATE != 8 && MR_ABLATE != 21) sa.tris[f] = t;\n"),
-    ("        quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap,", "        if (MR_ABLATE != 9) quad_setup_group(fc, sa, bins, have && slot < sa.quad_cap,"),
+    ("        quad_setup_group(fc, sa, bins, have, (int)(ls >> 2),", "        if (MR_ABLATE != 9) quad_setup_group(fc, sa, bins, have, (int)(ls >> 2),"),
     ("    if (b < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, b);", "    if (b < face_blocks) { if (MR_ABLATE != 10) tri_setup_block<PRE_XFORM>(fc, sa, bins, b); }"),
     ("    else edge_block(fc, sa, bins, b - face_blocks);", "    else if (MR_ABLATE < 11 || MR_ABLATE > 21) edge_block(fc, sa, bins, b - face_blocks);"),
+    # edges alone (no face workgroups, like 10), the quad set-up cut short: 50 after the extrusion, 51 after the clipping, 52 before the atomics
+    ("    // ---- clipping, one plane at a time\n", "    if (MR_ABLATE == 50) { if (have && gl == 0 && v[0] > 1e300) sa.sil_edges[0] = 1; return; }\n    // ---- clipping, one plane at a time\n"),
+    ("    const bool alive = n >= 3;                           // obj/triangular.py:322-323\n", "    if (MR_ABLATE == 51) { if (have && gl == 0 && v[0] > 1e300) sa.sil_edges[0] = n; return; }\n    const bool alive = n >= 3;                           // obj/triangular.py:322-323\n"),
+    ("    // the quad's record slot and its work items of 64 tiles", "    if (MR_ABLATE == 52) { if (boxed && gl == 0 && bx0 > 100000) sa.sil_edges[0] = bx1; return; }\n    // the quad's record slot and its work items of 64 tiles"),
     # faces alone (no edge workgroups), cut short: 12 after the transform, 13 after the index row, 14 before the survivor walk
     ("    uint8_t *status = sa.status;\n", "    uint8_t *status = sa.status;\n    if (MR_ABLATE == 12) { status[f] = (uint8_t)(A.sx + B.sy + C.sz > 1e300); return 0; }\n"),
     ("    const double *wa = sa.verts + (size_t)ia.x * 4,", "    if (MR_ABLATE == 13) { sa.status[f] = (uint8_t)(ia.x + ib.y + ic.z + ff == -12345); return 0; }\n    const double *wa = sa.verts + (size_t)ia.x * 4,"),
     ("    status[f] = FACE_OK;\n", "    status[f] = FACE_OK;\n    if (MR_ABLATE == 14) { status[f] = (uint8_t)(t.inv_den > 1e30f); return 0; }\n"),
     # 12 and up: no tile-order sort either (15: the whole face path alone, 16: 15 without the workgroup epilogue, 17: the sort alone)
-    ("    if (blockIdx.x == 0) { order_tiles_block(", "    if (blockIdx.x == 0) { if (MR_ABLATE < 12 || MR_ABLATE == 17 || MR_ABLATE > 21) order_tiles_block("),
+    ("    if (blockIdx.x == 0) { order_tiles_block(", "    if (blockIdx.x == 0) { if (MR_ABLATE < 12 || MR_ABLATE == 17 || (MR_ABLATE > 21 && MR_ABLATE < 50) || MR_ABLATE > 52) order_tiles_block("),
     ("    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);\n", "    if (MR_ABLATE == 16) return;\n    const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);\n"),
-    ("    if (b < face_blocks) { if (MR_ABLATE != 10) tri", "    if (b < face_blocks) { if (MR_ABLATE != 10 && MR_ABLATE != 17) tri"),
+    ("    if (b < face_blocks) { if (MR_ABLATE != 10) tri", "    if (b < face_blocks) { if (MR_ABLATE != 10 && MR_ABLATE != 17 && (MR_ABLATE < 50 || MR_ABLATE > 52)) tri"),
 ]
 for a, b in edits:
     assert s.count(a) == 1, a
