@@ -367,8 +367,10 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         unsigned int sfrags = 0;
         int round = 0;
         // SMALL_LANES lanes per pair; two where the list is longer than one round of those (a round is two
-        // dependent memory round trips whatever it holds: 65 pairs in two rounds cost twice what 64 do)
-        const int spl = n_small > (uint32_t)(TILE_PX / SMALL_LANES) ? SMALL_LANES / 2 : SMALL_LANES;
+        // dependent memory round trips whatever it holds: 65 pairs in two rounds cost twice what 64 do), eight
+        // where it is at most half a round (the lanes would idle otherwise; c2's larger triangles: -2 %)
+        const int spl = n_small > (uint32_t)(TILE_PX / SMALL_LANES) ? SMALL_LANES / 2
+                      : n_small > (uint32_t)(TILE_PX / (2 * SMALL_LANES)) ? SMALL_LANES : 2 * SMALL_LANES;
         const uint32_t per_round = (uint32_t)(TILE_PX / spl), my_pair = (uint32_t)(tid / spl);
         const int sub = tid % spl;
         for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
