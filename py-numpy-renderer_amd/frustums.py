@@ -105,11 +105,12 @@ class OverlayOps:
                     (np.clip(row + 1, 0, height - 1), wcol), (wrow, np.clip(col + 1, 0, width - 1)))
             for k, (r, c) in enumerate(sets):
                 lin = (r.astype(np.int64) * width + c).astype(np.int32)
+                # next point (later in the segment) with the same target: in a stable sort by target the points
+                # of one target follow each other in segment order
+                order = np.argsort(lin, kind="stable")
                 link = np.full(n, -1, np.int32)
-                last = {}
-                for i in range(n - 1, -1, -1):           # next point (later in the segment) with the same target
-                    link[i] = last.get(int(lin[i]), -1)
-                    last[int(lin[i])] = base + i
+                same = lin[order[1:]] == lin[order[:-1]]
+                link[order[:-1][same]] = base + order[1:][same]
                 target[k].append(lin)
                 nxt[k].append(link)
             zs.append(z)
