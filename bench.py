@@ -26,7 +26,8 @@ the reference rasterises every triangle in two passes) / time, summ
 The same line also carries the other regimes: one frame at a time (``latency_ms_single``,
 ``value_single_frame``), with the fragment counters on (``value_counters_on``: no depth cull of
 shadow quads) and the host-visible ``Scene.render()`` (``scene_render_ms_host``: packing, per-frame
-upload, render, device->host copy into a NumPy array).
+upload, render, device->host copy into a NumPy array; the camera is a NEW object on every call, as when it moves,
+so nothing is served from the host's caches -- ``*_same_camera`` is the same call with the cameras left alone).
 """
 import argparse
 import json
@@ -101,7 +102,7 @@ def cpu_baseline(scene, frags_per_frame, label, budget_s=12.0):
             "frames_per_s": round(n / dt, 3)}
 
 
-def swing_cameras(api, scene, n_views):
+def swing_cameras(api, scene, n_views, offset=0):
     """*n_views* camera pairs on a short arc around the scene's camera (0.05 degrees apart about the
     y axis): frames of a sequence differ in their per-frame constants, like these."""
     import numpy as np
@@ -111,7 +112,7 @@ def swing_cameras(api, scene, n_views):
     base = np.asarray(cam.position, dtype=np.float64)
     pairs = []
     for k in range(n_views):
-        a = np.deg2rad((k - n_views // 2) * 0.05)
+        a = np.deg2rad((k + offset - n_views // 2) * 0.05)
         pos = (base[0] * np.cos(a) + base[2] * np.sin(a), base[1], -base[0] * np.sin(a) + base[2] * np.cos(a))
         pairs.append((api.Camera(pos, cam.center, **kw), api.Camera(pos, cam.center, **kw)))
     return pairs
@@ -292,7 +293,7 @@ def main():
     counted.set_descriptors(descriptors(True, True))
     per_frame_counted = timed(counted, n_side)
 
-    host_ms = host_overlay_ms = None
+    host_ms = host_overlay_ms = host_same_ms = host_overlay_same_ms = None
     if rank == 0 and world == 1:
         # the drop-in call as a user makes it: Scene.render() returning the uint8 ndarray (packing of the
         # per-frame constants, upload, the three kernels, device->host copy into page-locked memory), first
@@ -300,20 +301,32 @@ def main():
         # upstream's default (overlay on: obj/core.py:638)
         scene.camera, scene.debug_camera = base_cameras
 
-        def host_median(n=15):
-            for _ in range(3):
-                scene.render(shadows=shadows)
+        def host_median(moving, n=15):
+            # moving: new Camera objects for every call, as in a sequence whose camera moves -- nothing the host
+            # derives from the cameras (matrices, planes, the overlay's line lists) can come from a cache
+            def step(k):
+                if moving:
+                    scene.camera, scene.debug_camera = swing_cameras(api, scene_base, 1, offset=k)[0]
+                return scene.render(shadows=shadows)
+            for k in range(3):
+                step(1000 + k)
             samples = []
-            for _ in range(n):
+            for k in range(n):
+                if moving:
+                    scene.camera, scene.debug_camera = base_cameras
                 t0 = time.perf_counter()
-                scene.render(shadows=shadows)
+                step(k + 1)
                 samples.append(time.perf_counter() - t0)
-            return float(np.median(samples) * 1e3)
+            scene.camera, scene.debug_camera = base_cameras
+            return sorted(samples)[len(samples) // 2] * 1e3
 
+        scene_base = scene
         scene.draw_debug_frustum = False
-        host_ms = host_median()
+        host_ms = host_median(True)
+        host_same_ms = host_median(False)
         scene.draw_debug_frustum = True
-        host_overlay_ms = host_median()
+        host_overlay_ms = host_median(True)
+        host_overlay_same_ms = host_median(False)
         scene.draw_debug_frustum = False
 
     if rank == 0:
@@ -361,6 +374,8 @@ def main():
             "scene_render_ms_host": None if host_ms is None else round(host_ms, 4),
             "value_scene_render_host": None if host_ms is None else round(frags_base / host_ms / 1e3, 2),
             "scene_render_ms_host_with_overlay": None if host_overlay_ms is None else round(host_overlay_ms, 4),
+            "scene_render_ms_host_same_camera": None if host_same_ms is None else round(host_same_ms, 4),
+            "scene_render_ms_host_with_overlay_same_camera": None if host_overlay_same_ms is None else round(host_overlay_same_ms, 4),
             "reference_numpy_mfrag_s": REFERENCE_MFRAGS[args.config],
             "gpu_ms_per_kernel": {k: round(v, 5) for k, v in ktimes.items()},
             "gpu_ms_per_kernel_solo": {k: round(v, 5) for k, v in ktimes_solo.items()},

@@ -221,6 +221,12 @@ int mr_render(mr_scene *scene, const mr_frame_desc *frame, uint8_t *out_rgb, mr_
 void *mr_host_alloc(uint64_t bytes);
 void mr_host_free(void *p);
 
+/* Host arithmetic, no device involved: out (m x p) = a (m x k) @ b (k x p) in float64, every element
+ * rn(a[i][0] * b[0][j]) followed by fma steps in ascending k -- the order the reference's NumPy / OpenBLAS stack
+ * uses for its 4x4 products (obj/core.py:383-405, obj/transformation.py), which the per-frame constants must
+ * reproduce bit for bit.  The Python mirror builds its matrices, planes and overlay polygons with it. */
+void mr_host_matmul_chain(const double *a, const double *b, double *out, int32_t m, int32_t k, int32_t p);
+
 /* Same, but leaves the uint8 band in device memory at d_out_rgb (a device pointer owned by
  * the caller, e.g. a torch tensor's data_ptr) and does not synchronise the host: work is
  * enqueued on `stream` (a hipStream_t; NULL = the library's own stream).  Used by the

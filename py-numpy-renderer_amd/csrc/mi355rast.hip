@@ -964,6 +964,19 @@ void *mr_host_alloc(uint64_t bytes)
     return p;
 }
 
+// out[i][j] = a[i][0] * b[0][j], then fma(a[i][k], b[k][j], .) for k = 1 .. K-1: the order NumPy's BLAS uses for
+// the reference's tiny host-side products, spelled out so that it is the same on any host.
+// Host arithmetic for the Python mirror's per-frame constants; no device involved.
+void mr_host_matmul_chain(const double *a, const double *b, double *out, int32_t m, int32_t k, int32_t p)
+{
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < p; ++j) {
+            double acc = a[(size_t)i * k] * b[j];
+            for (int x = 1; x < k; ++x) acc = std::fma(a[(size_t)i * k + x], b[(size_t)x * p + j], acc);
+            out[(size_t)i * p + j] = acc;
+        }
+}
+
 void mr_host_free(void *p)
 {
     if (p) (void)hipHostFree(p);

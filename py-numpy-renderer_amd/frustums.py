@@ -85,45 +85,49 @@ class OverlayOps:
     def __init__(self, camera, positioned_object, resolution):
         height, width = (int(v) for v in resolution)
         self.height, self.width = height, width
-        seg_first, seg_count, target, nxt, zs = [], [], [[] for _ in range(5)], [[] for _ in range(5)], []
-        base = 0
+        rows, cols, zs, counts = [], [], [], []
         for row, col, z in overlay_segments(camera, positioned_object):
-            n = len(z)
-            if n == 0:
+            if len(z) == 0:
                 continue
             # Python / NumPy index semantics: a negative index counts from the end; anything else out of
             # range raises IndexError in the reference (there the frame is lost; here the point is)
             ok = (row >= -height) & (row < height) & (col >= -width) & (col < width)
-            row, col, z = row[ok], col[ok], z[ok]
-            n = len(z)
-            if n == 0:
+            if not ok.all():
+                row, col, z = row[ok], col[ok], z[ok]
+            if len(z) == 0:
                 continue
-            wrow, wcol = row % height, col % width                     # the centre index wraps like Python's
-            # the neighbours are clipped from the RAW index (np.clip(x + i, 0, last)), so a point at -1
-            # wraps to the last row but its neighbours are row 0 (obj/frustums.py:97-103)
-            sets = ((wrow, wcol), (np.clip(row - 1, 0, height - 1), wcol), (wrow, np.clip(col - 1, 0, width - 1)),
-                    (np.clip(row + 1, 0, height - 1), wcol), (wrow, np.clip(col + 1, 0, width - 1)))
-            for k, (r, c) in enumerate(sets):
-                lin = (r.astype(np.int64) * width + c).astype(np.int32)
-                # next point (later in the segment) with the same target: in a stable sort by target the points
-                # of one target follow each other in segment order
-                order = np.argsort(lin, kind="stable")
-                link = np.full(n, -1, np.int32)
-                same = lin[order[1:]] == lin[order[:-1]]
-                link[order[:-1][same]] = base + order[1:][same]
-                target[k].append(lin)
-                nxt[k].append(link)
-            zs.append(z)
-            seg_first.append(base)
-            seg_count.append(n)
-            base += n
-        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(0, dt), dtype=dt)
-        self.seg_first = np.asarray(seg_first, np.int32)
-        self.seg_count = np.asarray(seg_count, np.int32)
-        self.target = np.ascontiguousarray(np.stack([cat(t, np.int32) for t in target]))      # (5, n_points)
-        self.next = np.ascontiguousarray(np.stack([cat(t, np.int32) for t in nxt]))
-        self.z = cat(zs, np.float64)
-        self.touched = np.unique(self.target).astype(np.int32) if self.z.size else np.zeros(0, np.int32)
+            rows.append(row); cols.append(col); zs.append(z); counts.append(len(z))
+        if not counts:
+            self.seg_first = self.seg_count = np.zeros(0, np.int32)
+            self.target = self.next = np.zeros((self.N_TARGETS, 0), np.int32)
+            self.z = np.zeros(0, np.float64)
+            self.touched = np.zeros(0, np.int32)
+            return
+        # all segments at once from here on (a few array operations instead of dozens per segment)
+        row = np.concatenate(rows).astype(np.int64)
+        col = np.concatenate(cols).astype(np.int64)
+        self.z = np.ascontiguousarray(np.concatenate(zs), dtype=np.float64)
+        self.seg_count = np.asarray(counts, np.int32)
+        self.seg_first = (np.cumsum(self.seg_count) - self.seg_count).astype(np.int32)
+        n = len(row)
+        segment = np.repeat(np.arange(len(counts), dtype=np.int64), self.seg_count)
+        wrow, wcol = row % height, col % width                          # the centre index wraps like Python's
+        # the neighbours are clipped from the RAW index (np.clip(x + i, 0, last)), so a point at -1
+        # wraps to the last row but its neighbours are row 0 (obj/frustums.py:97-103)
+        sets = ((wrow, wcol), (np.clip(row - 1, 0, height - 1), wcol), (wrow, np.clip(col - 1, 0, width - 1)),
+                (np.clip(row + 1, 0, height - 1), wcol), (wrow, np.clip(col + 1, 0, width - 1)))
+        self.target = np.empty((self.N_TARGETS, n), np.int32)
+        self.next = np.full((self.N_TARGETS, n), -1, np.int32)
+        for k, (r, c) in enumerate(sets):
+            lin = r * width + c
+            self.target[k] = lin
+            # next point (later in the SAME segment) with the same target: in a stable sort by (segment, target)
+            # the points of one target of one segment follow each other in segment order
+            key = segment * (height * width) + lin
+            order = np.argsort(key, kind="stable")
+            same = key[order[1:]] == key[order[:-1]]
+            self.next[k, order[:-1][same]] = order[1:][same]
+        self.touched = np.unique(self.target).astype(np.int32)
 
     @property
     def n_points(self):

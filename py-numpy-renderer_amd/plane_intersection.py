@@ -6,7 +6,7 @@ kept here for API parity with the reference's ``obj/plane_intersection.py:39-86`
 """
 import numpy as np
 
-from ._fp import dot_chain
+from ._fp import dot_chain, matmul_chain
 
 left, right, bottom, top, near, far = range(6)
 
@@ -44,19 +44,34 @@ def line_plane_intersection(line_point1, line_point2, plane_coefficients):
 
 
 def clipping(polygon_vertices, clipping_planes):
-    """Clip a convex polygon (k,4) against each plane in turn; returns an (m,4) array."""
-    polygon = [np.asarray(v, dtype=np.float64) for v in polygon_vertices]
+    """Clip a convex polygon (k,4) against each plane in turn; returns an (m,4) array.
+
+    The same walk as ``is_visible`` / ``line_plane_intersection`` vertex by vertex (the reference's
+    ``obj/plane_intersection.py:59-86``), with a plane's dot products taken for the whole polygon at once
+    (same fma chains, one call)."""
+    polygon = np.array([np.asarray(v, dtype=np.float64) for v in polygon_vertices], dtype=np.float64).reshape(-1, 4)
     for plane in clipping_planes:
-        kept = []
         count = len(polygon)
-        for i, current in enumerate(polygon):
-            following = polygon[(i + 1) % count]
-            cur_in, next_in = is_visible(current, plane), is_visible(following, plane)
-            if cur_in:
-                kept.append(current)
-            if cur_in != next_in:
-                hit = line_plane_intersection(following, current, plane)
-                if hit is not None:
-                    kept.append(hit)
-        polygon = kept
-    return np.array(polygon)
+        if count == 0:
+            break
+        plane = np.asarray(plane, dtype=np.float64)
+        dist = matmul_chain(polygon, plane.reshape(4, 1))[:, 0]          # dot_chain(plane, vertex) per vertex
+        inside = dist >= 0
+        nxt = np.arange(1, count + 1)
+        nxt[-1] = 0
+        following = polygon[nxt]
+        crossing = inside != inside[nxt]
+        kept = []
+        if crossing.any():
+            direction = polygon - following                              # line_plane_intersection(following, current, plane)
+            den = matmul_chain(direction, plane.reshape(4, 1))[:, 0]
+            dist_following = dist[nxt]
+        for i in range(count):
+            if inside[i]:
+                kept.append(polygon[i])
+            if crossing[i] and not abs(den[i]) < 1e-10:
+                weight = -dist_following[i] / den[i]
+                if 0 <= weight <= 1:
+                    kept.append(following[i] + weight * direction[i])
+        polygon = np.array(kept, dtype=np.float64).reshape(-1, 4)
+    return polygon
