@@ -3,6 +3,8 @@
 Same names and argument meaning as the reference's ``obj/transformation.py`` (row-vector
 convention: ``clip = v @ MVP``).  Every builder returns float64 unless noted.
 """
+import math
+
 import numpy as np
 
 from .constants import X, Y, SYSTEM, SUBSYSTEM, PROJECTION_TYPE, mat3x3  # noqa: F401 (re-exported)
@@ -58,10 +60,27 @@ def looka_at_translate(eye):
     return m
 
 
+def _unit3(v):
+    """``normalize`` of one 3-vector with scalar arithmetic: the same operations NumPy performs (squares, a
+    left-to-right sum, sqrt, three divisions), a dozen array calls fewer -- this runs for every frame whose camera moved."""
+    x, y, z = float(v[0]), float(v[1]), float(v[2])
+    length = math.sqrt((x * x + y * y) + z * z)
+    if length == 0:
+        length = 1.0
+    return np.array((x / length, y / length, z / length))
+
+
+def _cross3(a, b):
+    """``np.cross`` of two 3-vectors, component by component as NumPy does (two rounded products, one subtraction)."""
+    a0, a1, a2 = float(a[0]), float(a[1]), float(a[2])
+    b0, b1, b2 = float(b[0]), float(b[1]), float(b[2])
+    return np.array((a1 * b2 - a2 * b1, a2 * b0 - a0 * b2, a0 * b1 - a1 * b0))
+
+
 def _look_at_axes(eye, center, up):
-    forward = normalize(np.asarray(center) - np.asarray(eye)).ravel()
-    right = normalize(np.cross(up, forward)).ravel()
-    return right, np.cross(forward, right), forward
+    forward = _unit3(np.asarray(center, dtype=np.float64) - np.asarray(eye, dtype=np.float64))
+    right = _unit3(_cross3(up, forward))
+    return right, _cross3(forward, right), forward
 
 
 def look_at_rotate_lh(eye, center, up):
