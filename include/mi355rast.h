@@ -227,6 +227,19 @@ void mr_host_free(void *p);
  * reproduce bit for bit.  The Python mirror builds its matrices, planes and overlay polygons with it. */
 void mr_host_matmul_chain(const double *a, const double *b, double *out, int32_t m, int32_t k, int32_t p);
 
+/* Host arithmetic too: the statement lists of the debug-camera frustum overlay (what mr_scene_set_overlay takes),
+ * from the frustum's eight corners (8 x 4, already divided by w: CUBE @ inv(debug MVP), obj/frustums.py:52-53), the
+ * viewing camera's six planes (6 x 4), its MVP and viewport (4 x 4, row vectors), near / far, and whether the
+ * viewing camera sits inside the frustum (obj/frustums.py:57-60).  Replaces obj/frustums.py:61-103 +
+ * obj/line.py:6-16 on the host: clipping, projection, DDA, dashes, index wrapping, same-target links.
+ * _build leaves the lists in a per-thread buffer and reports their sizes; _fetch copies them into the caller's
+ * arrays (target / next: 5 x n_points, row-major; any pointer may be NULL). */
+int mr_host_overlay_build(const double *corners, const double *planes, const double *mvp, const double *viewport,
+                          double near_plane, double far_plane, int32_t camera_inside, int32_t height, int32_t width,
+                          int32_t *n_segments, int32_t *n_points, int32_t *n_touched);
+int mr_host_overlay_fetch(int32_t *seg_first, int32_t *seg_count, int32_t *target, int32_t *next, double *z,
+                          int32_t *touched);
+
 /* Same, but leaves the uint8 band in device memory at d_out_rgb (a device pointer owned by
  * the caller, e.g. a torch tensor's data_ptr) and does not synchronise the host: work is
  * enqueued on `stream` (a hipStream_t; NULL = the library's own stream).  Used by the

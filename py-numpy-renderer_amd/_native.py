@@ -100,6 +100,9 @@ _PROTOTYPES = {
     "mr_read_face_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mr_read_silhouette": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_host_matmul_chain": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "mr_host_overlay_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mr_host_overlay_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mr_debug_read_tile_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_debug_read_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_last_error": (C.c_char_p, []),

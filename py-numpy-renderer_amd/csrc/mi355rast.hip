@@ -15,6 +15,7 @@
 //
 // Built for gfx950 only, with -ffp-contract=off (see rast_math.h).
 #include "../../include/mi355rast.h"
+#include "host_overlay.h"
 
 #include <hip/hip_runtime.h>
 
@@ -687,6 +688,8 @@ FrameSlot *last_slot(mr_scene *sc)
 
 // ============================================================================ C ABI
 
+static thread_local mr_host::OverlayLists g_overlay_lists;
+
 extern "C" {
 
 int mr_abi_version(void) { return MR_ABI_VERSION; }
@@ -975,6 +978,39 @@ void mr_host_matmul_chain(const double *a, const double *b, double *out, int32_t
             for (int x = 1; x < k; ++x) acc = std::fma(a[(size_t)i * k + x], b[(size_t)x * p + j], acc);
             out[(size_t)i * p + j] = acc;
         }
+}
+
+// The debug-frustum overlay's statement lists on the host (host_overlay.h): build into a per-thread buffer, report
+// the sizes, then copy out into arrays of those sizes.
+int mr_host_overlay_build(const double *corners, const double *planes, const double *mvp, const double *viewport,
+                          double near_, double far_, int32_t camera_inside, int32_t height, int32_t width,
+                          int32_t *n_segments, int32_t *n_points, int32_t *n_touched)
+{
+    if (!corners || !planes || !mvp || !viewport || !n_segments || !n_points || !n_touched || height <= 0 || width <= 0)
+        return fail(MR_E_INVALID, "mr_host_overlay_build: bad argument");
+    static const int32_t faces[24] = { 2, 4, 5, 3,  0, 1, 7, 6,  0, 2, 3, 1,  5, 4, 6, 7,  3, 5, 7, 1,  4, 2, 0, 6 };
+    g_overlay_lists = mr_host::OverlayLists();
+    mr_host::build_overlay_lists(corners, faces, planes, mvp, viewport, near_, far_, camera_inside != 0, height, width, 13,
+                                 g_overlay_lists);
+    *n_segments = (int32_t)g_overlay_lists.seg_first.size();
+    *n_points = (int32_t)g_overlay_lists.z.size();
+    *n_touched = (int32_t)g_overlay_lists.touched.size();
+    return MR_OK;
+}
+
+int mr_host_overlay_fetch(int32_t *seg_first, int32_t *seg_count, int32_t *target, int32_t *next, double *z, int32_t *touched)
+{
+    const mr_host::OverlayLists &o = g_overlay_lists;
+    const size_t n = o.z.size();
+    if (seg_first) std::copy(o.seg_first.begin(), o.seg_first.end(), seg_first);
+    if (seg_count) std::copy(o.seg_count.begin(), o.seg_count.end(), seg_count);
+    for (int k = 0; k < 5; ++k) {
+        if (target) std::copy(o.target[k].begin(), o.target[k].end(), target + (size_t)k * n);
+        if (next) std::copy(o.next[k].begin(), o.next[k].end(), next + (size_t)k * n);
+    }
+    if (z) std::copy(o.z.begin(), o.z.end(), z);
+    if (touched) std::copy(o.touched.begin(), o.touched.end(), touched);
+    return MR_OK;
 }
 
 void mr_host_free(void *p)

@@ -82,3 +82,41 @@ def test_overlay_is_on_by_default_like_upstream(api):
     out = default.render()
     assert np.abs(out.astype(np.int16) - g["out"].astype(np.int16)).max() <= 1
     default.close()
+
+
+def test_native_list_builder_equals_the_numpy_walk():
+    """``mr_host_overlay_build`` (the overlay's lists in host C++, csrc/host_overlay.h) against the NumPy walk
+    that states what they are (frustums.OverlayOps, native=False): every array bit for bit, over random pairs of
+    viewing / debug cameras -- both handednesses, the viewing camera inside and outside the debug frustum
+    (dashed edges), frustums cut by the viewing planes, odd resolutions, points that wrap around the frame."""
+    import py_numpy_renderer_amd as pkg
+    from py_numpy_renderer_amd._native import load_library
+    from py_numpy_renderer_amd.frustums import OverlayOps
+    load_library()                                   # the helper is plain host code: no GPU needed
+    rng = np.random.default_rng(20)
+    fields = ("seg_first", "seg_count", "target", "next", "touched")
+    n_points = dashed = 0
+    for trial in range(160):
+        lh = trial % 3 == 0
+        system, subsystem = (pkg.SYSTEM.LH, pkg.SUBSYSTEM.OPENGL) if lh else (pkg.SYSTEM.RH, pkg.SUBSYSTEM.DIRECTX)
+        res = (int(rng.integers(40, 200)), int(rng.integers(40, 260)))
+        near = float(rng.choice([0.05, 0.1, 0.5, 1.0]))
+        kw = dict(fovy=float(rng.choice([30, 60, 90])), near=near, far=near + float(rng.choice([2.0, 20.0, 400.0])),
+                  backface_culling=True)
+        eye = rng.standard_normal(3) * 2 + np.array([0.5, 1.0, 2.0])
+        cam = pkg.Camera(tuple(eye), (0, 0, 0), **kw)
+        if trial % 4 == 0:
+            dbg = pkg.Camera(tuple(eye), (0, 0, 0), **kw)                      # the same frustum: border + diagonal
+        else:
+            kd = dict(kw, fovy=float(rng.choice([20, 45, 80])), near=float(rng.choice([0.2, 1.0])), far=float(rng.choice([3.0, 8.0])))
+            kd["far"] += kd["near"]
+            dbg = pkg.Camera(tuple(rng.standard_normal(3) * 1.5 + np.array([0.0, 1.0, 0.5])), tuple(rng.standard_normal(3) * 0.3), **kd)
+        scene = pkg.Scene(cam, pkg.Light((2, 3, 4)), debug_camera=dbg, resolution=res, system=system, subsystem=subsystem)
+        a = OverlayOps(scene.camera, scene.debug_camera, res, native=False)
+        b = OverlayOps(scene.camera, scene.debug_camera, res, native=True)
+        for f in fields:
+            assert np.array_equal(getattr(a, f), getattr(b, f)), (trial, f)
+        assert np.array_equal(a.z.view(np.uint64), b.z.view(np.uint64)), (trial, "z")
+        n_points += a.n_points
+        dashed += int(len(a.seg_count) > 0 and a.seg_count.min() < 30)
+    assert n_points > 20000 and dashed > 10          # the trials did draw something, short (dashed / clipped) segments included
