@@ -253,15 +253,17 @@ class DeviceRenderer:
     # -- scene upload ---------------------------------------------------------------------
     @staticmethod
     def _fingerprint(arr):
-        """Cheap identity of an array's CONTENT: where it lives, its layout, and a checksum of a strided
-        sample of ~64 elements (a few microseconds).  Catches replacement and wholesale in-place
-        edits; single-element pokes need ``Model.invalidate()``."""
+        """Cheap identity of an array's CONTENT: where it lives, its layout, and a checksum of ~64 WHOLE rows
+        spread evenly over the array (a few microseconds).  Catches replacement and wholesale in-place edits,
+        including an edit of a single column (every row changes, so every sampled row does; sampling flat
+        elements at a stride that shares a factor with the row width would skip whole columns); a poke at a
+        few single elements needs ``Model.invalidate()``."""
         if arr is None:
             return None
         a = np.asarray(arr)
-        flat = a.reshape(-1)
-        step = max(1, flat.size // 64)
-        return (a.__array_interface__["data"][0], a.shape, a.dtype.str, zlib.crc32(np.ascontiguousarray(flat[::step])))
+        rows = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(-1, 1)
+        step = max(1, rows.shape[0] // 64)
+        return (a.__array_interface__["data"][0], a.shape, a.dtype.str, zlib.crc32(np.ascontiguousarray(rows[::step])))
 
     @classmethod
     def _scene_signature(cls, scene):
@@ -326,6 +328,8 @@ class DeviceRenderer:
                int(scene.system), int(scene.subsystem))
         if getattr(self, "_overlay_key", None) == key:
             return
+        # the key holds ids: keep the objects alive while it is cached, so that no other camera or matrix can
+        # be given a recycled address and pass for them
         from .frustums import OverlayOps
         ops = OverlayOps(cam, dbg, scene.resolution)
         d = OverlayDesc()
@@ -336,6 +340,7 @@ class DeviceRenderer:
         _check(self.lib.mr_scene_set_overlay(self.handle, C.byref(d) if ops.n_points else None), "mr_scene_set_overlay")
         self._overlay_key = (id(cam), id(dbg), id(cam.__dict__.get("MVP")), id(dbg.__dict__.get("MVP")),
                              tuple(scene.resolution), int(scene.system), int(scene.subsystem))
+        self._overlay_refs = (cam, dbg, cam.__dict__.get("MVP"), dbg.__dict__.get("MVP"))
 
     # -- frames ---------------------------------------------------------------------------
     @staticmethod
@@ -362,6 +367,11 @@ class DeviceRenderer:
             self._pack_serial = getattr(self, "_pack_serial", 0) + 1
             self._packed = (None, pack_frame(scene, shadows))
             self._packed = (self._frame_key(scene, shadows), self._packed[1])    # the MVPs exist (and are cached) now
+            # the key identifies cameras, light and matrices by id(): hold them while the entry lives, so that
+            # CPython cannot hand their addresses to the objects of a later frame
+            cam = scene.camera
+            dbg = scene.debug_camera if scene.debug_camera is not None else cam
+            self._packed_refs = (cam, dbg, cam.__dict__.get("MVP"), dbg.__dict__.get("MVP"), scene.light, scene.skybox)
         return self._packed[1]
 
     def render(self, scene, shadows=True, row_band=None, keep_float=False, face_status=False, counters=True,

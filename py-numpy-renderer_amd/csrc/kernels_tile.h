@@ -182,6 +182,7 @@ struct TileArgs {
     int32_t *winner, *stencil;
     uint32_t *tile_stats;
     Counters *ctr, *next_ctr;     // this frame's counters; the next frame's (cleared here)
+    Sticky *sticky;               // overflow verdicts of the slot's earlier frames (see Sticky)
     int32_t *split_sten;          // [HEAVY0_MAX][HEAVY_SPLIT][TILE_PX] stencil counts of a split tile's parts
     uint32_t *split_arrive;       // [HEAVY0_MAX] parts that have left theirs (zero between frames)
     const uint32_t *order;        // ORDER_HEAD words, then the tiles in the order to render them (k_bin_work); null: row-major
@@ -210,7 +211,22 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     const bool counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
     const TriRec *__restrict__ tris = sh.tris;
 
-    if (blockIdx.x == 0 && tid == 0) *ta.next_ctr = Counters{};  // nobody touches the next frame's counters before this kernel ends
+    if (blockIdx.x == 0 && tid == 0) {
+        // The next frame's counter block is the previous frame's (double-buffered by parity; that frame is
+        // complete: same stream).  Its overflow verdicts move to the slot's sticky record before the block is
+        // cleared; nobody touches either before this kernel ends.
+        const Counters &old = *ta.next_ctr;
+        if (old.overflow | old.n_quads | old.n_work) {
+            Sticky &st = *ta.sticky;
+            st.overflow |= old.overflow;
+#pragma unroll
+            for (int c = 0; c < BIN_CLASSES; ++c) st.max_list[c] = max(st.max_list[c], old.max_list[c]);
+            st.n_work = max(st.n_work, old.n_work);
+            st.n_quads = max(st.n_quads, old.n_quads);
+            st.n_quads_drawn = max(st.n_quads_drawn, old.n_quads_drawn);
+        }
+        *ta.next_ctr = Counters{};
+    }
 
     // heaviest tiles first: entry blockIdx.x of the order k_bin_work left (see tile_class)
     uint32_t idx = blockIdx.x;
@@ -610,12 +626,14 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
 
     if (SPLIT && n_parts > 1) {
         // Leave this part's counts, then take a ticket.  Hand-off between workgroups on different CUs
-        // (MI355X_MICROARCH.md, inter-workgroup visibility): plain stores, every wave's stores drained
-        // (the barrier waits for vmcnt(0)), ONE agent-scope release, then the relaxed ticket; the last
-        // arriver does ONE agent-scope acquire (invalidates its CU's L1) behind a barrier, then plain loads.
+        // (MI355X_MICROARCH.md, inter-workgroup visibility): plain stores, EVERY storing wave drains its
+        // own stores (s_waitcnt vmcnt(0): a workgroup barrier does not wait for vector memory), the
+        // barrier, ONE agent-scope release, then the relaxed ticket; the last arriver does ONE agent-scope
+        // acquire (invalidates its CU's L1) behind a barrier, then plain loads.
         __shared__ uint32_t s_ticket;
         int32_t *mine = ta.split_sten + ((size_t)entry * HEAVY_SPLIT + part) * TILE_PX;
         mine[lp] = sten;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -94,7 +94,8 @@ struct FrameSlot {
     uint32_t bin_cap[mr::BIN_CLASSES] = { 0, 0, 0 }, work_cap = 0, quad_cap = 0;
     int bins_zeroed_for = 0;
 
-    mr::Counters *h_counters = nullptr;           // pinned
+    mr::Counters *h_counters = nullptr;           // pinned: the last frame's counters, then (h_sticky) the slot's sticky record
+    mr::Sticky *h_sticky = nullptr;
     hipEvent_t ev_ring[EVENT_RING][N_MARKS] = {};
     uint8_t ev_marks[EVENT_RING] = {};            // 0: the frame recorded no events, 1: frame + tile kernel, 2: every stage
     hipEvent_t *ev = ev_ring[0];
@@ -122,6 +123,8 @@ struct FrameSlot {
     }
     // the counters are double-buffered by frame parity: a frame's tile kernel clears the next frame's
     mr::Counters *ctr(uint64_t frame) const { return d_counters.as<mr::Counters>() + (frame & 1); }
+    // overflow verdicts of the frames before the last one (rast_types.h, Sticky): behind the two counter blocks
+    mr::Sticky *sticky() const { return reinterpret_cast<mr::Sticky *>(d_counters.as<mr::Counters>() + 2); }
 };
 
 constexpr int MAX_SLOTS = 32;
@@ -445,7 +448,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     HIP_TRY(fs->d_sil.ensure((size_t)fs->quad_cap * 2 * sizeof(int32_t)));
     {
         const void *had = fs->d_counters.p;
-        HIP_TRY(fs->d_counters.ensure(2 * sizeof(Counters)));
+        HIP_TRY(fs->d_counters.ensure(2 * sizeof(Counters) + sizeof(Sticky)));
         if (fs->d_counters.p != had) HIP_TRY(hipMemsetAsync(fs->d_counters.p, 0, fs->d_counters.cap, stream));
     }
     HIP_TRY(fs->d_bin_count.ensure((size_t)(BIN_CLASSES * n_tiles + 1) * 4));
@@ -465,7 +468,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     if (fc.flags & MR_FRAME_KEEP_FLOAT) HIP_TRY(fs->d_frame.ensure(npx * 3 * sizeof(float)));
     if (!fs->events_ok) {
         for (auto &set : fs->ev_ring) for (auto &e : set) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipHostMalloc((void **)&fs->h_counters, sizeof(Counters), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&fs->h_counters, sizeof(Counters) + sizeof(Sticky), hipHostMallocDefault));
+        fs->h_sticky = reinterpret_cast<Sticky *>(fs->h_counters + 1);
         fs->events_ok = true;
     }
     fs->ev = fs->ev_ring[fs->frames_enqueued % EVENT_RING];
@@ -547,7 +551,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ta.winner = keep ? fs->d_winner.as<int32_t>() : nullptr;
     ta.stencil = keep ? fs->d_stencil.as<int32_t>() : nullptr;
     ta.tile_stats = fs->d_tile_stats.as<uint32_t>();
-    ta.ctr = ctr; ta.next_ctr = next_ctr;
+    ta.ctr = ctr; ta.next_ctr = next_ctr; ta.sticky = fs->sticky();
     // Heaviest-first order shortens the critical path of a frame that has the device to itself.  When the
     // scene is being rendered from several streams at once (frames in flight), the next frame's work fills
     // the tail anyway and bunching the heavy tiles at the front only makes them compete: measured on MI355X
@@ -624,6 +628,7 @@ int fetch_counters(mr_scene *sc, FrameSlot *fs, bool reduce)
         fs->stats_reduced = true;
     }
     HIP_TRY(hipMemcpyAsync(fs->h_counters, ctr, sizeof(Counters), hipMemcpyDeviceToHost, fs->stream));
+    HIP_TRY(hipMemcpyAsync(fs->h_sticky, fs->sticky(), sizeof(Sticky), hipMemcpyDeviceToHost, fs->stream));
     return MR_OK;
 }
 
@@ -651,20 +656,33 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
     s.gpu_ms_tile = span(3, 4);
     s.gpu_ms_copy = with_copy && timed ? span(4, 5) : 0.f;
     s.gpu_ms_total = span(0, with_copy ? 5 : 4);
+    // the verdicts of the last frame and of every frame of this slot since the host last looked (Sticky)
+    mr::Sticky &st = *fs->h_sticky;
+    const uint32_t overflow = c.overflow | st.overflow;
+    const uint32_t n_work = std::max(c.n_work, st.n_work), n_quads = std::max(c.n_quads, st.n_quads);
+    const uint32_t n_quads_drawn = std::max(c.n_quads_drawn, st.n_quads_drawn);
     bool grown = false;
-    if (c.overflow) {
+    if (overflow) {
         for (int cls = 0; cls < mr::BIN_CLASSES; ++cls)
-            if (c.overflow & (1u << cls)) {
-                uint32_t want = std::max(c.max_list[cls] + c.max_list[cls] / 2, fs->bin_cap[cls] * 2);
+            if (overflow & (1u << cls)) {
+                const uint32_t longest = std::max(c.max_list[cls], st.max_list[cls]);
+                uint32_t want = std::max(longest + longest / 2, fs->bin_cap[cls] * 2);
                 uint32_t cap = 64;
                 while (cap < want) cap <<= 1;
                 sc->bin_cap[cls] = std::max(sc->bin_cap[cls], cap);
             }
-        if (c.overflow & 8u) sc->work_cap = std::max(sc->work_cap, c.n_work + c.n_work / 2 + 1024);
-        if (c.overflow & 16u) sc->quad_cap = std::max(sc->quad_cap, std::max(c.n_quads_drawn + c.n_quads_drawn / 2 + 64, fs->quad_cap * 2));
+        if (overflow & 8u) sc->work_cap = std::max(sc->work_cap, n_work + n_work / 2 + 1024);
+        if (overflow & 16u) sc->quad_cap = std::max(sc->quad_cap, std::max(n_quads_drawn + n_quads_drawn / 2 + 64, fs->quad_cap * 2));
         grown = true;
     }
-    if (c.n_quads > fs->quad_cap) { sc->quad_cap = std::max(sc->quad_cap, c.n_quads + c.n_quads / 2 + 64); grown = true; }
+    if (n_quads > fs->quad_cap) { sc->quad_cap = std::max(sc->quad_cap, n_quads + n_quads / 2 + 64); grown = true; }
+    if (grown) {
+        // acted on: the device's record and the last frame's block start clean (stream order puts this in front of
+        // the slot's next frame, whose tile kernel would fold that block into the record again)
+        (void)hipMemsetAsync(fs->ctr(fs->frames_enqueued - 1), 0, sizeof(mr::Counters), fs->stream);
+        (void)hipMemsetAsync(fs->sticky(), 0, sizeof(mr::Sticky), fs->stream);
+        st = mr::Sticky{};
+    }
     return grown ? MR_E_OVERFLOW : MR_OK;
 }
 

@@ -179,4 +179,16 @@ struct alignas(128) Counters {
 };
 static_assert(sizeof(Counters) == 128 * 5, "Counters layout");
 
+// What must outlive a frame's counters.  The counters are double-buffered by frame parity and a frame's tile
+// kernel clears the block of the frame after it, i.e. the block of the frame BEFORE it: the overflow verdicts of a
+// frame enqueued without host synchronisation would be gone two frames later.  Before clearing, the tile kernel
+// folds them into this record (one per frame slot), which only the host resets, after it has acted on it.
+struct alignas(64) Sticky {
+    unsigned int overflow;                    // OR of Counters::overflow
+    unsigned int max_list[BIN_CLASSES];       // maxima of the rest
+    unsigned int n_work, n_quads, n_quads_drawn;
+    unsigned int pad[9];
+};
+static_assert(sizeof(Sticky) == 64, "Sticky layout");
+
 }  // namespace mr

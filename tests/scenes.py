@@ -190,6 +190,91 @@ def gizmo_files():
     return GENERATED
 
 
+def fins_obj():
+    """A non-manifold "fin" mesh: four vertical spine edges, each shared by THREE or FOUR triangles that fan
+    out from it at different angles and with mixed windings (obj/triangular.py:286-302 toggles an edge once per
+    light-facing incident face: with three or four of them an edge is added, discarded and added again, and
+    keeps the orientation of the LAST insert).  No closed surface anywhere: every outer edge has one face."""
+    # x offset, z offset, [(fin angle in degrees, faces the light at (2, 3, 4)?)]: the winding of every fin is chosen
+    # so that it does or does not face that light -- spine 1: one of three does (the edge is inserted once), spine 2:
+    # three of four (inserted, discarded, inserted again), spine 3: two of four (inserted and discarded: not on the
+    # silhouette), spine 4: all three (the surviving entry has the orientation of the third face)
+    wanted = (
+        (-0.75, 0.0, ((10, False), (130, True), (250, False))),
+        (-0.25, 0.1, ((40, True), (100, True), (200, False), (320, True))),
+        (0.25, -0.1, ((0, True), (90, False), (180, True), (270, False))),
+        (0.75, 0.0, ((60, True), (180, True), (300, True))),
+    )
+    # the normal of (bottom, top, tip) is (sin a, 0, -cos a) up to scale
+    spines = tuple((sx, sz, tuple((ang, 1 if ((2 * math.sin(math.radians(ang)) - 4 * math.cos(math.radians(ang))) > 0) == lit
+                                   else -1) for ang, lit in fins)) for sx, sz, fins in wanted)
+    verts, normals, faces = [], [], []
+    for sx, sz, fins in spines:
+        bottom, top = len(verts) + 1, len(verts) + 2
+        verts += [(sx, -0.45, sz), (sx, 0.35, sz)]
+        for ang, wind in fins:
+            a = math.radians(ang)
+            tip = (sx + 0.22 * math.cos(a), -0.05 + 0.002 * ang / 10.0, sz + 0.22 * math.sin(a))
+            verts.append(tip)
+            tri = (bottom, top, len(verts)) if wind > 0 else (top, bottom, len(verts))
+            pa, pb, pc = (np.array(verts[i - 1]) for i in tri)
+            n = np.cross(pb - pa, pc - pa)
+            n = n / np.linalg.norm(n)
+            normals.append(tuple(n))
+            faces.append((tri, len(normals)))
+    lines = ["v %.6f %.6f %.6f" % v for v in verts] + ["vn %.6f %.6f %.6f" % n for n in normals]
+    lines += ["f " + " ".join("%d//%d" % (i, ni) for i in tri) for tri, ni in faces]
+    return _write_if_changed(os.path.join(GENERATED, "fins.obj"), "\n".join(lines) + "\n")
+
+
+def wall_files():
+    """A 3 x 3 wall of quads, every quad in a ``usemtl`` group of its own: nine materials in one library
+    (different Kd / Ks / Ns, whole and fractional exponents, two of them with a ``map_Kd``) -- with the floor's
+    and the cube's that is more than the tile kernel keeps in LDS."""
+    import shutil
+    os.makedirs(GENERATED, exist_ok=True)
+    for src, dst in (("grid.tga", "wall_grid.tga"), ("floor_diffuse.tga", "wall_floor.tga")):
+        if not os.path.exists(os.path.join(GENERATED, dst)):
+            shutil.copy(os.path.join(ASSETS, src), os.path.join(GENERATED, dst))
+    mtl, obj = ["# nine materials"], ["mtllib wall.mtl"]
+    for j in range(4):
+        for i in range(4):
+            obj.append("v %.6f %.6f %.6f" % (-0.9 + 0.6 * i, -0.5 + 0.45 * j, -0.3 + 0.05 * i))
+    obj += ["vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1", "vn 0 0 1"]
+    for k in range(9):
+        i, j = k % 3, k // 3
+        mtl += ["", f"newmtl m{k}", "Ns %s" % (8 + 7 * k if k % 2 == 0 else 5.5 + 3.25 * k),
+                "Kd %.3f %.3f %.3f" % (0.15 + 0.09 * k, 0.9 - 0.08 * k, 0.3 + 0.05 * ((k * 5) % 9)),
+                "Ks %.3f %.3f %.3f" % (0.2 + 0.08 * k, 0.5, 1.0 - 0.1 * k)]
+        if k == 4:
+            mtl.append("map_Kd wall_grid.tga")
+        if k == 7:
+            mtl.append("map_Kd wall_floor.tga")
+        a, b, c, d = j * 4 + i + 1, j * 4 + i + 2, (j + 1) * 4 + i + 2, (j + 1) * 4 + i + 1
+        obj += [f"usemtl m{k}", f"f {a}/1/1 {b}/2/1 {c}/3/1 {d}/4/1"]
+    _write_if_changed(os.path.join(GENERATED, "wall.mtl"), "\n".join(mtl) + "\n")
+    return _write_if_changed(os.path.join(GENERATED, "wall.obj"), "\n".join(obj) + "\n")
+
+
+def neg_uv_obj():
+    """A tilted quad cut into a 3 x 3 grid whose texture coordinates run from -0.6 to 1.4 in both directions:
+    negative ``vt`` truncate to negative texel indices, which Python wraps from the far side of the texture
+    (obj/core.py:138-143); values above 1 are clipped (u) or go negative through ``1 - v`` (rows)."""
+    lines = []
+    for j in range(4):
+        for i in range(4):
+            lines.append("v %.6f %.6f %.6f" % (-0.8 + 1.6 * i / 3, -0.5 + 1.1 * j / 3, 0.2 - 0.25 * j / 3))
+    for j in range(4):
+        for i in range(4):
+            lines.append("vt %.6f %.6f" % (-0.6 + 2.0 * i / 3, -0.6 + 2.0 * j / 3))
+    lines.append("vn 0 0.2 1")
+    for j in range(3):
+        for i in range(3):
+            a, b, c, d = j * 4 + i + 1, j * 4 + i + 2, (j + 1) * 4 + i + 2, (j + 1) * 4 + i + 1
+            lines.append(f"f {a}/{a}/1 {b}/{b}/1 {c}/{c}/1 {d}/{d}/1")
+    return _write_if_changed(os.path.join(GENERATED, "neg_uv.obj"), "\n".join(lines) + "\n")
+
+
 # --------------------------------------------------------------------------- building blocks
 def _std_cameras(api, **over):
     kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
@@ -410,6 +495,34 @@ def tetra_ortho(api, resolution=(120, 160)):
                   system=api.SYSTEM.LH, subsystem=api.SUBSYSTEM.OPENGL)
 
 
+def fins_nonmanifold(api, resolution=(150, 200)):
+    """Silhouette edges with three and four incident faces (obj/triangular.py:286-302), culling off so that
+    both sides of the fins are drawn, over a floor that catches their shadow volumes."""
+    cam, dbg = _std_cameras(api, backface_culling=False)
+    fins = api.Model.load_model(fins_obj())
+    return _scene(api, cam, dbg, _std_light(api), resolution, [fins, _floor(api)])
+
+
+def wall_nine_materials(api, resolution=(150, 200)):
+    """More materials in one scene than the tile kernel stages in LDS: nine in the wall's library, the cube's
+    (map_Kd + map_Ks) and the floor's."""
+    cam, dbg = _std_cameras(api)
+    wall = api.Model.load_model(wall_files())
+    cube = api.Model.load_model(os.path.join(ASSETS, "cube", "cube.obj"))
+    cube.normals = -cube.normals
+    cube = cube @ api.scale(0.3) @ api.translation((0.2, -0.3, 0.6))
+    return _scene(api, cam, dbg, _std_light(api, specular_strength=0.3), resolution, [wall, cube, _floor(api)])
+
+
+def quad_negative_uv(api, resolution=(150, 200)):
+    """Texture coordinates below 0 and above 1 on a textured, normal-mapped quad (obj/core.py:138-143)."""
+    cam, dbg = _std_cameras(api)
+    quad = api.Model.load_model(neg_uv_obj())
+    quad.textures.register("diffuse", os.path.join(ASSETS, "grid.tga"), normalize=False)
+    quad.textures.register("normals", os.path.join(ASSETS, "floor_nm_tangent.tga"), tangent=True)
+    return _scene(api, cam, dbg, _std_light(api), resolution, [quad, _floor(api)])
+
+
 # name -> (builder, kwargs); the small ones have full golden buffers committed
 SMALL = {
     "cube_small": (cube_small, {}),
@@ -428,6 +541,9 @@ SMALL = {
     "tetra_ortho": (tetra_ortho, {}),
     "cube_tetra_nodepth": (cube_tetra_nodepth, {}),
     "gizmos_small": (gizmos_small, {}),
+    "fins_nonmanifold": (fins_nonmanifold, {}),
+    "wall_nine_materials": (wall_nine_materials, {}),
+    "quad_negative_uv": (quad_negative_uv, {}),
 }
 
 # BASELINE.json configs at full size: only the uint8 frame, winner map, stencil and z row sums are kept

@@ -231,6 +231,71 @@ def test_work_lists_grow_on_overflow(api):
     scene.close()
 
 
+def test_overflow_in_an_earlier_frame_is_not_forgotten(api):
+    """Frames enqueued without host synchronisation: a work list that overflows in ONE frame must still be
+    reported after later frames of the same stream that overflow nothing (the frame counters are
+    double-buffered and recycled; the verdict has to survive that), and once the lists have been grown and
+    the host has acted, a clean frame must read as clean again."""
+    import torch
+    scene = scenes.build(api, "diablo_floor_small")
+    want = scene.render()
+    backend = scene._backend()
+    h, w = (int(v) for v in scene.resolution)
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    looking_at = (scene.camera, scene.debug_camera)
+    kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
+    looking_away = (api.Camera((0.5, 1, 2), (1, 2, 4), **kw), api.Camera((0.5, 1, 2), (1, 2, 4), **kw))
+
+    def enqueue(cameras, n):
+        scene.camera, scene.debug_camera = cameras
+        for _ in range(n):
+            backend.render_device(scene, out.data_ptr(), stream.cuda_stream, shadows=True, no_timing=True)
+
+    enqueue(looking_at, 1)
+    stream.synchronize()
+    assert not backend.overflowed()
+    backend.set_list_capacities(small_pairs=4, big_pairs=2, quads=3)
+    enqueue(looking_at, 1)                       # overflows its tile lists
+    enqueue(looking_away, 5)                     # nothing on screen: these overflow nothing
+    stream.synchronize()
+    assert backend.overflowed(), "the overflow of an earlier frame of the stream was forgotten"
+    for _ in range(8):                           # lists were grown; the frame may need to grow them once or twice more
+        enqueue(looking_at, 1)
+        enqueue(looking_away, 2)
+        stream.synchronize()
+        if not backend.overflowed():
+            break
+    else:
+        raise AssertionError("work lists kept overflowing")
+    enqueue(looking_at, 1)
+    stream.synchronize()
+    assert not backend.overflowed()
+    assert np.array_equal(out.cpu().numpy(), want)
+    scene.close()
+
+
+def test_frame_constant_cache_holds_what_it_is_keyed_on(api):
+    """The per-frame constants and the overlay lists are cached under the ids of the cameras and their MVPs:
+    the cache keeps those objects alive, so a camera created later cannot be mistaken for one of them, and a
+    loop that replaces the cameras every frame renders every view."""
+    scene = scenes.build(api, "cube_outward")
+    scene.draw_debug_frustum = True
+    backend = scene._backend()
+    kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
+    frames = []
+    for k in range(6):
+        pos = (0.5 + 0.3 * (k % 3), 1, 2)
+        scene.camera, scene.debug_camera = api.Camera(pos, (0, 0, 0), **kw), api.Camera(pos, (0, 0, 0), **kw)
+        frames.append(scene.render())
+        assert backend._packed_refs[0] is scene.camera and backend._packed_refs[2] is scene.camera.MVP
+        assert backend._overlay_refs[1] is scene.debug_camera
+    for k in range(3):
+        assert np.array_equal(frames[k], frames[k + 3])
+        assert not np.array_equal(frames[k], frames[(k + 1) % 3])
+    scene.close()
+
+
 def test_errors_are_loud(api):
     from py_numpy_renderer_amd import _native
     lib = _native.load_library()

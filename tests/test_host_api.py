@@ -195,3 +195,21 @@ def test_raw_edge_ids_are_kept_for_negative_indices():
     assert np.array_equal(wrapped, house.faces[..., 0])
     cube = pack_scene(_one_model_scene(Model.load_model(os.path.join(scenes.ASSETS, "cube", "cube.obj")))).models[0]
     assert cube.edge_ids is None
+
+
+@pytest.mark.parametrize("rows", [4096, 100002, 100352])
+def test_change_detector_sees_an_in_place_edit_of_any_column(rows):
+    """The scene change detector fingerprints whole rows spread over the array: editing one column of the
+    vertices in place (a natural way to animate) changes every row, so it must change the fingerprint --
+    whatever the row count's common factors with the row width."""
+    from py_numpy_renderer_amd._native import DeviceRenderer
+    rng = np.random.default_rng(rows)
+    verts = rng.standard_normal((rows, 4)).astype(np.float32)
+    faces = rng.integers(0, rows, (rows // 2, 3, 4)).astype(np.int32)
+    for arr, cols in ((verts, 4), (faces.reshape(len(faces), -1), 12)):
+        for col in range(cols):
+            before = DeviceRenderer._fingerprint(arr)
+            arr[:, col] += 1
+            assert DeviceRenderer._fingerprint(arr) != before, f"column {col} of {arr.shape}"
+    assert DeviceRenderer._fingerprint(None) is None
+    assert DeviceRenderer._fingerprint(np.zeros(5, np.float32)) != DeviceRenderer._fingerprint(np.ones(5, np.float32))
