@@ -143,12 +143,34 @@ __device__ __forceinline__ uint8_t gamma_u8(float x, const float *lut)
     return (uint8_t)k;
 }
 
+// What shading reads of the frame constants, as values: fetched in one go where the shading phase begins (a few
+// wide scalar loads) instead of one scalar load and one wait at every first use along the way.
+struct LightConst {
+    double camera_pos[3], light_pos[3], light_dir[3], light_color[3], light_ambient[3];
+    double specular_strength, att_constant, att_linear, att_quadratic, spot_edge0, spot_edge1;
+    int32_t light_type;
+};
+__device__ __forceinline__ LightConst light_const(const FrameConst &fc)
+{
+    LightConst lc;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        lc.camera_pos[j] = fc.camera_pos[j]; lc.light_pos[j] = fc.light_pos[j]; lc.light_dir[j] = fc.light_dir[j];
+        lc.light_color[j] = fc.light_color[j]; lc.light_ambient[j] = fc.light_ambient[j];
+    }
+    lc.specular_strength = fc.specular_strength;
+    lc.att_constant = fc.att_constant; lc.att_linear = fc.att_linear; lc.att_quadratic = fc.att_quadratic;
+    lc.spot_edge0 = fc.spot_edge0; lc.spot_edge1 = fc.spot_edge1;
+    lc.light_type = fc.light_type;
+    return lc;
+}
+
 __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v); }
 
 // Colour of one covered pixel: the reference's two shading passes collapsed: the
 // pixel shows its winner face, lit (obj/triangular.py:149-171) where the stencil count is zero,
 // ambient only (obj/triangular.py:135-147) where it is not.  `mat` may live in LDS.
-__device__ __forceinline__ void shade_pixel(const FrameConst &fc, const TriRec &t, const TriAttr &at, const Material &mat,
+__device__ __forceinline__ void shade_pixel(const LightConst &fc, const TriRec &t, const TriAttr &at, const Material &mat,
                                             int px, int py, bool lit, float rgb[3])
 {
     const uint8_t ff = (uint8_t)(t.flags >> 8);

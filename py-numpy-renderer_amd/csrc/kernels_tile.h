@@ -57,15 +57,18 @@ struct SweepCache {
     uint32_t meta;                    // pixel of sample s in bits 8s..8s+7, "sample s is cached" in bit 16+s, samples walked from bit 20
 };
 
+// the frame's limits a tile clamps its pixel boxes to (values, not the frame constants: see kernargs())
+struct TileBounds { int width, band_y0, band_y1; };
+
 // SWEEP 0 with `cache`: fills it.  SWEEP 1 with `first` > 0: skips the lane's first `first` samples (the cache
 // answered for them).
 template <int SWEEP>
-__device__ __forceinline__ void small_pair(const FrameConst &fc, const TriRec &t, int gx, int gy, bool rh,
+__device__ __forceinline__ void small_pair(const TileBounds &tb, const TriRec &t, int gx, int gy, bool rh,
                                            unsigned long long *s_key, int *s_win, int sub, int lanes, unsigned int &frags,
                                            SweepCache *cache = nullptr, int first = 0)
 {
-    const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, fc.width));
-    const int y0 = max(max((int)t.y0, gy), fc.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), fc.band_y1);
+    const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, tb.width));
+    const int y0 = max(max((int)t.y0, gy), tb.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), tb.band_y1);
     const bool single = (t.flags & TF_SINGLE_BOX) != 0;
     // Model.depth_test == False (obj/triangular.py:117): the face's fragments are tested, never written to z.
     // The pixel then shows the LAST face in order among those that pass against the final z (see k_tile).
@@ -164,6 +167,10 @@ static_assert(ORDER_CLASSES == 8, "tile_class");
 // frame the launch is bound by the tiles' total work, which the repeated rasterisation only adds to
 // (measured on MI355X, c4: 86 -> 90 us whole frame; a rank of 8: 56 -> 38 us).
 constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = 128;
+#ifndef MR_TILE_WAVES
+#define MR_TILE_WAVES 5
+#endif
+constexpr int K_TILE_WAVES = MR_TILE_WAVES;              // wavefronts per SIMD the tile kernel's register budget allows
 constexpr int SPLIT_FRONT = HEAVY_SPLIT * HEAVY0_MAX;     // extra workgroups of a k_tile<true> launch
 
 // estimated cost of a tile in ~0.1 us from its list lengths (fitted to measured tile times on MI355X)
@@ -189,13 +196,30 @@ struct TileArgs {
     uint8_t *tile_class;          // [n_tiles] what this frame leaves for the next: 1 + the tile's cost class
 };
 
+struct TileKernArgs { FrameConst fc; TileArgs ta; ShadeArgs sh; };
+
+// The kernel's arguments as ONE PHASE of the kernel sees them: a reference into the kernarg segment through a
+// pointer the compiler cannot see through, so the scalar loads of what a phase uses are issued in that phase and
+// their registers are dead after it.  Read as plain by-value arguments, the ~1 KB of frame constants and 25
+// pointers were all fetched at the top of the kernel and kept for its whole length: 106 SGPRs, and beyond those
+// the compiler parked them in lanes of two VGPRs -- ~110 v_writelane at the head of every wavefront and up to
+// 390 v_readlane along it, a fifth of the vector instructions k_tile issued (rocprofv3 SQ_INSTS_VALU).
+template <class T>
+__device__ __forceinline__ const T &kernargs()
+{
+    typedef const __attribute__((address_space(4))) char *kernarg_ptr;
+    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T *)(const char *)p;
+}
+
 // One workgroup per tile, one pixel per thread.  Tiles are dealt to workgroups in plain
 // row-major order, i.e. round-robin over the XCDs: heavy tiles cluster on the screen, and an
 // XCD-contiguous mapping (tried first) left six of the eight XCDs idle behind the two that
 // owned the mesh and its shadow.
 template <bool SPLIT>      // SPLIT: the heaviest tiles' shadow quads are shared out over HEAVY_SPLIT workgroups (see HEAVY_SPLIT)
-__global__ void __launch_bounds__(TILE_PX, 5)
-k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
+__global__ void __launch_bounds__(TILE_PX, K_TILE_WAVES)
+k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), phase by phase
 {
     __shared__ unsigned long long s_key[TILE_PX];
     __shared__ int s_win[TILE_PX];
@@ -206,234 +230,255 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     __shared__ unsigned long long s_mat[MAT_LDS * sizeof(Material) / 8];
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int n_tiles = fc.tiles_x * fc.tiles_y;
-    const bool rh = fc.system == 1;
-    const bool counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
-    const TriRec *__restrict__ tris = sh.tris;
-
-    if (blockIdx.x == 0 && tid == 0) {
-        // The next frame's counter block is the previous frame's (double-buffered by parity; that frame is
-        // complete: same stream).  Its overflow verdicts move to the slot's sticky record before the block is
-        // cleared; nobody touches either before this kernel ends.
-        const Counters &old = *ta.next_ctr;
-        if (old.overflow | old.n_quads | old.n_work) {
-            Sticky &st = *ta.sticky;
-            st.overflow |= old.overflow;
-#pragma unroll
-            for (int c = 0; c < BIN_CLASSES; ++c) st.max_list[c] = max(st.max_list[c], old.max_list[c]);
-            st.n_work = max(st.n_work, old.n_work);
-            st.n_quads = max(st.n_quads, old.n_quads);
-            st.n_quads_drawn = max(st.n_quads_drawn, old.n_quads_drawn);
-        }
-        *ta.next_ctr = Counters{};
-    }
-
-    // heaviest tiles first: entry blockIdx.x of the order k_bin_work left (see tile_class)
-    uint32_t idx = blockIdx.x;
-    int tile = 0, part = 0, n_parts = 1, entry = 0;
-    if (SPLIT) {
-        const uint32_t n0 = ta.order ? min(ta.order[0], (uint32_t)HEAVY0_MAX) : 0u;   // the class whose quads are shared out
-        if (idx < (uint32_t)SPLIT_FRONT) {
-            entry = (int)idx / HEAVY_SPLIT;
-            part = (int)idx % HEAVY_SPLIT;
-            n_parts = counters ? 1 : HEAVY_SPLIT;
-            if (entry >= (int)n0 || part >= n_parts) return;
-            idx = (uint32_t)entry;
-        } else {
-            idx = idx - (uint32_t)SPLIT_FRONT + n0;
-        }
-    }
-    if (idx >= (uint32_t)n_tiles) return;
-    tile = ta.order ? (int)ta.order[ORDER_HEAD + idx] : (int)idx;
-    const int ltr = tile / fc.tiles_x;                    // local tile row
-    const int gx = (tile % fc.tiles_x) * TILE_W, gy = tile_row_frame(fc, ltr) * TILE_H;
     const int lp = tid;                                   // pixel of this thread inside the tile
-    const int px = gx + (lp & (TILE_W - 1)), py = gy + lp / TILE_W;
-    const bool live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
-    const double dpx = (double)px, dpy = (double)py;
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 
-    // list lengths (a list that ran over its capacity is truncated; the host grows it and re-renders)
-    const uint32_t n_small_raw = ta.bin_count[tile], n_big_raw = ta.bin_count[n_tiles + tile],
-                   n_quad_raw = ta.bin_count[2 * n_tiles + tile];
-    const uint32_t n_small = min(n_small_raw, ta.cap[0]), n_big = min(n_big_raw, ta.cap[1]), n_quad = min(n_quad_raw, ta.cap[2]);
-    // the heaviest tiles are the frame's critical path: their wavefronts go first wherever they
-    // compete with a lighter tile's for a SIMD's issue slots
-    const uint32_t cost = tile_cost(n_small_raw, n_big_raw, n_quad_raw);
-    if (cost >= 900u) __builtin_amdgcn_s_setprio(3);
-    else if (cost >= 400u) __builtin_amdgcn_s_setprio(1);
-    const uint32_t *__restrict__ small_items = ta.items[0] + (size_t)tile * ta.cap[0];
-    const uint32_t *__restrict__ big_items = ta.items[1] + (size_t)tile * ta.cap[1];
-    const uint32_t *__restrict__ quad_items = ta.items[2] + (size_t)tile * ta.cap[2];
+    // ---- 0. which tile, and what it lists
+    int tile = 0, part = 0, n_parts = 1, entry = 0, n_tiles, ltr, gx, gy, px, py;
+    bool rh, counters, live, mat_lds;
+    uint32_t n_small_raw, n_big_raw, n_quad_raw, n_small, n_big, n_quad, cost;
+    unsigned long long t_start;
+    {
+        const TileKernArgs &ka = kernargs<TileKernArgs>();
+        const FrameConst &fc = ka.fc;
+        const TileArgs &ta = ka.ta;
+        const ShadeArgs &sh = ka.sh;
+        n_tiles = fc.tiles_x * fc.tiles_y;
+        rh = fc.system == 1;
+        counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
 
-    // Nothing listed for this tile (a third of a typical frame): its pixels show the background, which
-    // the host has finalised already, or the skybox (no lists to walk, no barriers but the gamma table's).
-    // Shadow quads over it only matter to the counters.
-    const bool sky_tile = (fc.flags & MR_FRAME_SKYBOX) && sh.sky;
-    if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (sky_tile || (fc.background_u8 >> 24)) &&
-        !sh.frame && !ta.zbuf) {
-        if (part != 0) return;                            // (a tile that was heavy a frame ago: one part will do)
-        uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
-        if (sky_tile) {
-            s_gamma[tid] = sh.gamma_lut[tid];
-            if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
-            float rgb[3] = { 0.f, 0.f, 0.f };
-            if (live) sky_color(fc, sh.sky, px, py, rgb);
-            __syncthreads();
-            if (live) {
+        if (blockIdx.x == 0 && tid == 0) {
+            // The next frame's counter block is the previous frame's (double-buffered by parity; that frame is
+            // complete: same stream).  Its overflow verdicts move to the slot's sticky record before the block is
+            // cleared; nobody touches either before this kernel ends.
+            const Counters &old = *ta.next_ctr;
+            if (old.overflow | old.n_quads | old.n_work) {
+                Sticky &st = *ta.sticky;
+                st.overflow |= old.overflow;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
+                for (int c = 0; c < BIN_CLASSES; ++c) st.max_list[c] = max(st.max_list[c], old.max_list[c]);
+                st.n_work = max(st.n_work, old.n_work);
+                st.n_quads = max(st.n_quads, old.n_quads);
+                st.n_quads_drawn = max(st.n_quads_drawn, old.n_quads_drawn);
             }
-        } else if (live) {
-            o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
+            *ta.next_ctr = Counters{};
         }
-        if (tid == 0) {
-            uint32_t *rec = ta.tile_stats + (size_t)tile * TILE_REC;
-            for (int k = 0; k < TILE_REC; ++k) rec[k] = 0;
-            rec[7] = n_quad_raw;
-            rec[8] = rec[10] = rec[11] = (uint32_t)t_start;
-            rec[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            ta.bin_count[2 * n_tiles + tile] = 0;
-            ta.tile_class[tile] = (uint8_t)ORDER_CLASSES;
+
+        // heaviest tiles first: entry blockIdx.x of the order k_setup left (see tile_class)
+        uint32_t idx = blockIdx.x;
+        if (SPLIT) {
+            const uint32_t n0 = ta.order ? min(ta.order[0], (uint32_t)HEAVY0_MAX) : 0u;   // the class whose quads are shared out
+            if (idx < (uint32_t)SPLIT_FRONT) {
+                entry = (int)idx / HEAVY_SPLIT;
+                part = (int)idx % HEAVY_SPLIT;
+                n_parts = counters ? 1 : HEAVY_SPLIT;
+                if (entry >= (int)n0 || part >= n_parts) return;
+                idx = (uint32_t)entry;
+            } else {
+                idx = idx - (uint32_t)SPLIT_FRONT + n0;
+            }
         }
-        return;
+        if (idx >= (uint32_t)n_tiles) return;
+        tile = ta.order ? (int)ta.order[ORDER_HEAD + idx] : (int)idx;
+        ltr = tile / fc.tiles_x;                          // local tile row
+        gx = (tile % fc.tiles_x) * TILE_W; gy = tile_row_frame(fc, ltr) * TILE_H;
+        px = gx + (lp & (TILE_W - 1)); py = gy + lp / TILE_W;
+        live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
+        t_start = __builtin_amdgcn_s_memrealtime();
+
+        // list lengths (a list that ran over its capacity is truncated; the host grows it and re-renders)
+        n_small_raw = ta.bin_count[tile]; n_big_raw = ta.bin_count[n_tiles + tile]; n_quad_raw = ta.bin_count[2 * n_tiles + tile];
+        n_small = min(n_small_raw, ta.cap[0]); n_big = min(n_big_raw, ta.cap[1]); n_quad = min(n_quad_raw, ta.cap[2]);
+        // the heaviest tiles are the frame's critical path: their wavefronts go first wherever they
+        // compete with a lighter tile's for a SIMD's issue slots
+        cost = tile_cost(n_small_raw, n_big_raw, n_quad_raw);
+        if (cost >= 900u) __builtin_amdgcn_s_setprio(3);
+        else if (cost >= 400u) __builtin_amdgcn_s_setprio(1);
+
+        // Nothing listed for this tile (a third of a typical frame): its pixels show the background, which
+        // the host has finalised already, or the skybox (no lists to walk, no barriers but the gamma table's).
+        // Shadow quads over it only matter to the counters.
+        const bool sky_tile = (fc.flags & MR_FRAME_SKYBOX) && sh.sky;
+        if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (sky_tile || (fc.background_u8 >> 24)) &&
+            !sh.frame && !ta.zbuf) {
+            if (part != 0) return;                        // (a tile that was heavy a frame ago: one part will do)
+            uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
+            if (sky_tile) {
+                s_gamma[tid] = sh.gamma_lut[tid];
+                if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
+                float rgb[3] = { 0.f, 0.f, 0.f };
+                if (live) sky_color(fc, sh.sky, px, py, rgb);
+                __syncthreads();
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
+                }
+            } else if (live) {
+                o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
+            }
+            if (tid == 0) {
+                uint32_t *rec = ta.tile_stats + (size_t)tile * TILE_REC;
+                for (int k = 0; k < TILE_REC; ++k) rec[k] = 0;
+                rec[7] = n_quad_raw;
+                rec[8] = rec[10] = rec[11] = (uint32_t)t_start;
+                rec[9] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                ta.bin_count[2 * n_tiles + tile] = 0;
+                ta.tile_class[tile] = (uint8_t)ORDER_CLASSES;
+            }
+            return;
+        }
+        if (tid < TILE_STATS) s_cnt[tid] = 0;
+        s_gamma[tid] = sh.gamma_lut[tid];
+        if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
+        mat_lds = fc.n_materials <= MAT_LDS;
+        if (mat_lds && tid < fc.n_materials * (int)(sizeof(Material) / 8))
+            s_mat[tid] = reinterpret_cast<const unsigned long long *>(sh.materials)[tid];
     }
-    if (tid < TILE_STATS) s_cnt[tid] = 0;
-    s_gamma[tid] = sh.gamma_lut[tid];
-    if (tid == 0) s_gamma[GAMMA_LUT_SIZE - 1] = sh.gamma_lut[GAMMA_LUT_SIZE - 1];
-    const bool mat_lds = fc.n_materials <= MAT_LDS;
-    if (mat_lds && tid < fc.n_materials * (int)(sizeof(Material) / 8))
-        s_mat[tid] = reinterpret_cast<const unsigned long long *>(sh.materials)[tid];
+    const double dpx = (double)px, dpy = (double)py;
 
     // ---- 1. big pairs, one pixel per thread (obj/triangular.py:72-118)
     double zbest = rh ? INFINITY : -INFINITY;
     int best = -1;
-    unsigned int frags = 0;
-    // The records of up to 64 pairs are copied to LDS once per workgroup, 16 bytes per lane and step
-    // (the staging area of the shadow quads, not in use yet), and every lane then reads the pair it is
-    // testing at the same LDS address (a broadcast read).  Each wavefront fetching the records itself,
-    // one per lane, and handing them round with v_readlane cost ~45 vector instructions per pair and
-    // wavefront on top of the arithmetic; scalar loads cost a dependent memory round trip per pair.
-    constexpr int TRI_U4 = (int)(sizeof(TriRec) / 16);
-    static_assert(WAVE * TRI_U4 <= QUAD_BATCH * QUAD_STAGE_U4, "big-pair records are staged in the quad area");
-    // LATE == false: the faces that write z.  LATE == true (only in scenes that have a model with
-    // depth_test == False, after the tile's final z is known): those that do not -- they own the pixel
-    // when they pass against the final z and come later in face order than the current owner.
-    auto big_pairs = [&](const bool late) {
-        for (uint32_t base = 0; base < n_big; base += WAVE) {
-            const int n = (int)min((uint32_t)WAVE, n_big - base);
-            if (base || late) __syncthreads();            // the staging area is free
-            for (int i = tid; i < n * TRI_U4; i += TILE_PX) {
-                const int q = i / TRI_U4, piece = i - q * TRI_U4;
-                s_quad[i] = reinterpret_cast<const uint4 *>(tris + big_items[base + q])[piece];
+    {
+        const TileKernArgs &ka = kernargs<TileKernArgs>();
+        const FrameConst &fc = ka.fc;
+        const TileArgs &ta = ka.ta;
+        const ShadeArgs &sh = ka.sh;
+        // (what the loops below read of the arguments is fetched here, once: a load through the opaque pointer is
+        // not hoisted out of a loop by the compiler when it sits under a condition)
+        const TriRec *__restrict__ tris = sh.tris;
+        const TriAttr *__restrict__ attrs = sh.attrs;
+        const TriClip *__restrict__ clips = ta.clips;
+        const uint32_t *__restrict__ small_items = ta.items[0] + (size_t)tile * ta.cap[0];
+        const uint32_t *__restrict__ big_items = ta.items[1] + (size_t)tile * ta.cap[1];
+        const bool same_clip = fc.same_clip != 0, has_no_depth = fc.has_no_depth != 0;
+        const TileBounds tb = { fc.width, fc.band_y0, fc.band_y1 };
+        unsigned int frags = 0;
+        // The records of up to 64 pairs are copied to LDS once per workgroup, 16 bytes per lane and step
+        // (the staging area of the shadow quads, not in use yet), and every lane then reads the pair it is
+        // testing at the same LDS address (a broadcast read).  Each wavefront fetching the records itself,
+        // one per lane, and handing them round with v_readlane cost ~45 vector instructions per pair and
+        // wavefront on top of the arithmetic; scalar loads cost a dependent memory round trip per pair.
+        constexpr int TRI_U4 = (int)(sizeof(TriRec) / 16);
+        static_assert(WAVE * TRI_U4 <= QUAD_BATCH * QUAD_STAGE_U4, "big-pair records are staged in the quad area");
+        // LATE == false: the faces that write z.  LATE == true (only in scenes that have a model with
+        // depth_test == False, after the tile's final z is known): those that do not -- they own the pixel
+        // when they pass against the final z and come later in face order than the current owner.
+        auto big_pairs = [&](const bool late) {
+            for (uint32_t base = 0; base < n_big; base += WAVE) {
+                const int n = (int)min((uint32_t)WAVE, n_big - base);
+                if (base || late) __syncthreads();        // the staging area is free
+                for (int i = tid; i < n * TRI_U4; i += TILE_PX) {
+                    const int q = i / TRI_U4, piece = i - q * TRI_U4;
+                    s_quad[i] = reinterpret_cast<const uint4 *>(tris + big_items[base + q])[piece];
+                }
+                __syncthreads();
+                for (int j = 0; j < n; ++j) {
+                    const TriRec &t = *reinterpret_cast<const TriRec *>(s_quad + j * TRI_U4);
+                    const uint32_t flags = t.flags;
+                    const bool nodepth = ((flags >> 8) & FF_NO_DEPTH) != 0;
+                    if (late && !nodepth) continue;
+                    const int f = t.face;
+                    const bool single = (flags & TF_SINGLE_BOX) != 0;
+                    bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
+                    float u, v, w;
+                    tri_bary(t, dpx, dpy, single, u, v, w);
+                    in = in && u >= 0 && v >= 0 && w >= 0;
+                    const unsigned long long m = __ballot(in);
+                    if (!m) continue;
+                    if (!late) frags += (unsigned int)__popcll(m);
+                    if (nodepth && !late) continue;
+                    if (flags & TF_CLIP) {
+                        if (in) {
+                            const TriClip &c = clips[f];
+                            const TriAttr &at = attrs[f];
+                            double p[3];
+                            persp_bary(at.dp, u, v, w, single, p);
+                            in = inside_clip(p, c.clip) && (same_clip || inside_clip(p, c.clipd));
+                        }
+                    }
+                    const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
+                    if (late) {
+                        if (in && (rh ? z <= zbest : z >= zbest) && f > best) best = f;
+                    } else {
+                        // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
+                        const bool closer = rh ? (z < zbest) : (z > zbest);
+                        if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
+                    }
+                }
+            }
+        };
+        big_pairs(false);
+        if (n_small) { s_key[lp] = z_key(zbest); s_win[lp] = -1; }     // the small pairs' LDS z-buffer starts from the big pairs' z
+        __syncthreads();                                  // s_cnt is zeroed, the LDS tables are loaded
+        if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
+        if (n_small) {
+            // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
+            // The second sweep (who owns the final z?) needs every sample's z key again.  For the first
+            // SWEEP_CACHE_ROUNDS rounds a lane leaves the keys of its first SWEEP_CACHE_K samples in LDS (the staging
+            // area of the shadow quads, not in use yet: 12 KB, exactly), with the face; the second sweep then
+            // compares those without the record, the barycentrics or the depth -- a mesh triangle of a few pixels is
+            // all cache.  Lanes with more samples, later rounds and faces that do not write z walk again.
+            unsigned long long (*c_key)[SWEEP_CACHE_K][TILE_PX] =
+                reinterpret_cast<unsigned long long (*)[SWEEP_CACHE_K][TILE_PX]>(s_quad);
+            uint32_t (*c_meta)[TILE_PX] = reinterpret_cast<uint32_t (*)[TILE_PX]>(
+                reinterpret_cast<unsigned long long *>(s_quad) + SWEEP_CACHE_ROUNDS * SWEEP_CACHE_K * TILE_PX);
+            uint32_t (*c_face)[TILE_PX] = c_meta + SWEEP_CACHE_ROUNDS;
+            static_assert(SWEEP_CACHE_ROUNDS * TILE_PX * (SWEEP_CACHE_K * 8 + 8) <= (int)sizeof(s_quad), "sweep cache fits the quad area");
+            unsigned int sfrags = 0;
+            int round = 0;
+            // SMALL_LANES lanes per pair; two where the list is longer than one round of those (a round is two
+            // dependent memory round trips whatever it holds: 65 pairs in two rounds cost twice what 64 do), eight
+            // where it is at most half a round (the lanes would idle otherwise; c2's larger triangles: -2 %)
+            const int spl = n_small > (uint32_t)(TILE_PX / SMALL_LANES) ? SMALL_LANES / 2
+                          : n_small > (uint32_t)(TILE_PX / (2 * SMALL_LANES)) ? SMALL_LANES : 2 * SMALL_LANES;
+            const uint32_t per_round = (uint32_t)(TILE_PX / spl), my_pair = (uint32_t)(tid / spl);
+            const int sub = tid % spl;
+            for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
+                const TriRec t = tris[small_items[i]];
+                if (round < SWEEP_CACHE_ROUNDS) {
+                    SweepCache sc;
+                    small_pair<0>(tb, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags, &sc);
+                    const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
+#pragma unroll
+                    for (int c = 0; c < SWEEP_CACHE_K; ++c) c_key[round][c][tid] = sc.key[c];
+                    c_meta[round][tid] = nodepth ? (sc.meta & 0xfff00000u) : sc.meta;      // nothing cached for a face that writes no z
+                    c_face[round][tid] = (uint32_t)t.face | (nodepth ? 0x80000000u : 0u);
+                } else {
+                    small_pair<0>(tb, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags);
+                }
+            }
+            if (sfrags) atomicAdd(&s_cnt[0], sfrags);
+            __syncthreads();
+
+            // winners: a big pair keeps its face where its z survived (an atomic like the small pairs' sweep: the
+            // largest face index among those at the final z, in any order)
+            const unsigned long long kfinal = s_key[lp];
+            if (best >= 0 && kfinal == z_key(zbest)) atomicMax(&s_win[lp], best);
+            round = 0;
+            for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
+                int first = 0;
+                if (round < SWEEP_CACHE_ROUNDS) {
+                    const uint32_t meta = c_meta[round][tid], cf = c_face[round][tid];
+                    const int walked = (int)(meta >> 20);
+                    const bool nodepth = (cf >> 31) != 0;
+#pragma unroll
+                    for (int c = 0; c < SWEEP_CACHE_K; ++c)
+                        if ((meta >> (16 + c)) & 1u) {
+                            const int p = (int)((meta >> (8 * c)) & 0xffu);
+                            if (s_key[p] == c_key[round][c][tid]) atomicMax(&s_win[p], (int)(cf & 0x7fffffffu));
+                        }
+                    if (!nodepth && walked <= SWEEP_CACHE_K) continue;     // the cache answered for every sample of this lane
+                    first = nodepth ? 0 : SWEEP_CACHE_K;
+                }
+                const TriRec t = tris[small_items[i]];
+                small_pair<1>(tb, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags, nullptr, first);
             }
             __syncthreads();
-            for (int j = 0; j < n; ++j) {
-                const TriRec &t = *reinterpret_cast<const TriRec *>(s_quad + j * TRI_U4);
-                const uint32_t flags = t.flags;
-                const bool nodepth = ((flags >> 8) & FF_NO_DEPTH) != 0;
-                if (late && !nodepth) continue;
-                const int f = t.face;
-                const bool single = (flags & TF_SINGLE_BOX) != 0;
-                bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
-                float u, v, w;
-                tri_bary(t, dpx, dpy, single, u, v, w);
-                in = in && u >= 0 && v >= 0 && w >= 0;
-                const unsigned long long m = __ballot(in);
-                if (!m) continue;
-                if (!late) frags += (unsigned int)__popcll(m);
-                if (nodepth && !late) continue;
-                if (flags & TF_CLIP) {
-                    if (in) {
-                        const TriClip &c = ta.clips[f];
-                        const TriAttr &at = sh.attrs[f];
-                        double p[3];
-                        persp_bary(at.dp, u, v, w, single, p);
-                        in = inside_clip(p, c.clip) && (fc.same_clip || inside_clip(p, c.clipd));
-                    }
-                }
-                const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
-                if (late) {
-                    if (in && (rh ? z <= zbest : z >= zbest) && f > best) best = f;
-                } else {
-                    // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
-                    const bool closer = rh ? (z < zbest) : (z > zbest);
-                    if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
-                }
-            }
+            best = s_win[lp];
+            zbest = z_unkey(kfinal);
         }
-    };
-    big_pairs(false);
-    if (n_small) { s_key[lp] = z_key(zbest); s_win[lp] = -1; }     // the small pairs' LDS z-buffer starts from the big pairs' z
-    __syncthreads();                                      // s_cnt is zeroed, the LDS tables are loaded
-    if (lane == 0 && frags) atomicAdd(&s_cnt[0], frags);
-    if (n_small) {
-        // ---- 2. small pairs, SMALL_LANES lanes per triangle, z into the LDS z-buffer
-        // The second sweep (who owns the final z?) needs every sample's z key again.  For the first
-        // SWEEP_CACHE_ROUNDS rounds a lane leaves the keys of its first SWEEP_CACHE_K samples in LDS (the staging
-        // area of the shadow quads, not in use yet: 12 KB, exactly), with the face; the second sweep then
-        // compares those without the record, the barycentrics or the depth -- a mesh triangle of a few pixels is
-        // all cache.  Lanes with more samples, later rounds and faces that do not write z walk again.
-        unsigned long long (*c_key)[SWEEP_CACHE_K][TILE_PX] =
-            reinterpret_cast<unsigned long long (*)[SWEEP_CACHE_K][TILE_PX]>(s_quad);
-        uint32_t (*c_meta)[TILE_PX] = reinterpret_cast<uint32_t (*)[TILE_PX]>(
-            reinterpret_cast<unsigned long long *>(s_quad) + SWEEP_CACHE_ROUNDS * SWEEP_CACHE_K * TILE_PX);
-        uint32_t (*c_face)[TILE_PX] = c_meta + SWEEP_CACHE_ROUNDS;
-        static_assert(SWEEP_CACHE_ROUNDS * TILE_PX * (SWEEP_CACHE_K * 8 + 8) <= (int)sizeof(s_quad), "sweep cache fits the quad area");
-        unsigned int sfrags = 0;
-        int round = 0;
-        // SMALL_LANES lanes per pair; two where the list is longer than one round of those (a round is two
-        // dependent memory round trips whatever it holds: 65 pairs in two rounds cost twice what 64 do), eight
-        // where it is at most half a round (the lanes would idle otherwise; c2's larger triangles: -2 %)
-        const int spl = n_small > (uint32_t)(TILE_PX / SMALL_LANES) ? SMALL_LANES / 2
-                      : n_small > (uint32_t)(TILE_PX / (2 * SMALL_LANES)) ? SMALL_LANES : 2 * SMALL_LANES;
-        const uint32_t per_round = (uint32_t)(TILE_PX / spl), my_pair = (uint32_t)(tid / spl);
-        const int sub = tid % spl;
-        for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
-            const TriRec t = tris[small_items[i]];
-            if (round < SWEEP_CACHE_ROUNDS) {
-                SweepCache sc;
-                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags, &sc);
-                const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
-#pragma unroll
-                for (int c = 0; c < SWEEP_CACHE_K; ++c) c_key[round][c][tid] = sc.key[c];
-                c_meta[round][tid] = nodepth ? (sc.meta & 0xfff00000u) : sc.meta;      // nothing cached for a face that writes no z
-                c_face[round][tid] = (uint32_t)t.face | (nodepth ? 0x80000000u : 0u);
-            } else {
-                small_pair<0>(fc, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags);
-            }
-        }
-        if (sfrags) atomicAdd(&s_cnt[0], sfrags);
-        __syncthreads();
-
-        // winners: a big pair keeps its face where its z survived (an atomic like the small pairs' sweep: the
-        // largest face index among those at the final z, in any order)
-        const unsigned long long kfinal = s_key[lp];
-        if (best >= 0 && kfinal == z_key(zbest)) atomicMax(&s_win[lp], best);
-        round = 0;
-        for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {
-            int first = 0;
-            if (round < SWEEP_CACHE_ROUNDS) {
-                const uint32_t meta = c_meta[round][tid], cf = c_face[round][tid];
-                const int walked = (int)(meta >> 20);
-                const bool nodepth = (cf >> 31) != 0;
-#pragma unroll
-                for (int c = 0; c < SWEEP_CACHE_K; ++c)
-                    if ((meta >> (16 + c)) & 1u) {
-                        const int p = (int)((meta >> (8 * c)) & 0xffu);
-                        if (s_key[p] == c_key[round][c][tid]) atomicMax(&s_win[p], (int)(cf & 0x7fffffffu));
-                    }
-                if (!nodepth && walked <= SWEEP_CACHE_K) continue;     // the cache answered for every sample of this lane
-                first = nodepth ? 0 : SWEEP_CACHE_K;
-            }
-            const TriRec t = tris[small_items[i]];
-            small_pair<1>(fc, t, gx, gy, rh, s_key, s_win, sub, spl, sfrags, nullptr, first);
-        }
-        __syncthreads();
-        best = s_win[lp];
-        zbest = z_unkey(kfinal);
+        if (has_no_depth) big_pairs(true);
     }
-    if (fc.has_no_depth) big_pairs(true);
     const bool covered = live && best >= 0;
     const unsigned long long t_raster = __builtin_amdgcn_s_memrealtime();
 
@@ -446,6 +491,12 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     unsigned int qfrags = 0, qupd = 0;
     // without the counters only the frame is the contract: the stencil matters where a triangle was drawn
     if (n_quad && (counters || __syncthreads_or(covered))) {
+        const TileKernArgs &ka = kernargs<TileKernArgs>();
+        const FrameConst &fc = ka.fc;
+        const TileArgs &ta = ka.ta;
+        const uint32_t *__restrict__ quad_items = ta.items[2] + (size_t)tile * ta.cap[2];
+        const QuadRec *__restrict__ quads = ta.quads;
+        const double f_plus_n = fc.f_plus_n, f_minus_n = fc.f_minus_n, two_nf = fc.two_nf;     // fetched once, see above
         // most and least favourable covered z of this wavefront's strip (see the depth verdicts below)
         double zlim = rh ? -INFINITY : INFINITY, zhard = rh ? INFINITY : -INFINITY;
         if (covered) zlim = zhard = zbest;
@@ -467,10 +518,10 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
             for (int i = tid; i < n * QUAD_STAGE_U4; i += TILE_PX) {
                 const int q = i / QUAD_STAGE_U4, piece = i - q * QUAD_STAGE_U4;
                 const uint32_t id = quad_items[qbase + q];
-                const QuadRec *src = ta.quads + id;
+                const QuadRec *src = quads + id;
                 uint4 val = reinterpret_cast<const uint4 *>(src)[piece];
                 if (piece == 3) {
-                    const double a0 = fc.f_plus_n * src->nz, b0 = fc.two_nf * src->nz;
+                    const double a0 = f_plus_n * src->nz, b0 = two_nf * src->nz;
                     val = make_uint4((uint32_t)__double2loint(a0), (uint32_t)__double2hiint(a0),
                                      (uint32_t)__double2loint(b0), (uint32_t)__double2hiint(b0));
                 } else if (piece >= 5 && (piece & 1) && !src->is_front) {
@@ -535,10 +586,10 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                 const double slack = 1e-12 * fmax(fabs(za), fabs(zb)) +
                                      1e-15 * ((fabs(h.nx) * xb + fabs(h.ny) * yb) + fabs(h.d)) * fabs(inz);
                 const double zs_lo = fmin(za, zb) - slack, zs_hi = fmax(za, zb) + slack;
-                const double den_lo = fc.f_plus_n - zs_hi * fc.f_minus_n, den_hi = fc.f_plus_n - zs_lo * fc.f_minus_n;
-                const bool sane = fc.two_nf > 0 && fc.f_minus_n > 0 && den_lo > 1e-9 * fc.f_plus_n && h.nz != 0 &&
+                const double den_lo = f_plus_n - zs_hi * f_minus_n, den_hi = f_plus_n - zs_lo * f_minus_n;
+                const bool sane = two_nf > 0 && f_minus_n > 0 && den_lo > 1e-9 * f_plus_n && h.nz != 0 &&
                                   fabs(inz) < 1e300 && den_hi < 1e300;
-                const double lo = fc.two_nf * (1.0 - 1e-12), hi = fc.two_nf * (1.0 + 1e-12);
+                const double lo = two_nf * (1.0 - 1e-12), hi = two_nf * (1.0 + 1e-12);
                 // rh: a pixel passes when zbuf >= zq; lh: when zbuf <= zq
                 const bool none = rh ? lo > zlim * den_hi : hi < zlim * den_lo;
                 const bool all = rh ? hi <= zhard * den_lo : lo >= zhard * den_hi;
@@ -576,7 +627,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                 if (em & 4) in = in & inner(ea2, eb2);
                 if (em & 8) in = in & inner(ea3, eb3);
                 if (em & 16) {                              // clipped polygons with 5+ vertices are rare
-                    const QuadRec *q = ta.quads + s_id[j];
+                    const QuadRec *q = quads + s_id[j];
                     for (int i = 4; i < nv; ++i) {
                         const double ax = dpx - q->e[i].sx, ay = dpy - q->e[i].sy;
                         const double cr = ax * q->e[i].ey - ay * q->e[i].ex;
@@ -601,7 +652,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                 const double nzq = __hiloint2double((int)p1.y, (int)p1.x), q_d = __hiloint2double((int)p1.w, (int)p1.z);
                 const double t = (q_nx * dpx + q_ny * dpy) + q_d;
                 const double a0 = d2(p3.x, p3.y), b0 = d2(p3.z, p3.w);          // f_plus_n * nz, two_nf * nz (staging)
-                const double tf = t * fc.f_minus_n;
+                const double tf = t * f_minus_n;
                 const double den = a0 + tf;
                 const double prod = zbest * den;
                 const double e = prod - b0;
@@ -612,7 +663,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
                 const bool unsure = in && !(clear && fabs(den) > 2e-4 * (fabs(a0) + fabs(tf)));
                 if (__ballot(unsure)) {
                     if (unsure) {
-                        const double z = linearize_z(fc, -t / nzq);
+                        const double z = two_nf / (f_plus_n - (-t / nzq) * f_minus_n);     // linearize_z (obj/core.py:226-228)
                         pass = rh ? (zbest >= z) : (zbest <= z);
                     }
                 }
@@ -631,6 +682,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
         // barrier, ONE agent-scope release, then the relaxed ticket; the last arriver does ONE agent-scope
         // acquire (invalidates its CU's L1) behind a barrier, then plain loads.
         __shared__ uint32_t s_ticket;
+        const TileArgs &ta = kernargs<TileKernArgs>().ta;
         int32_t *mine = ta.split_sten + ((size_t)entry * HEAVY_SPLIT + part) * TILE_PX;
         mine[lp] = sten;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -656,14 +708,19 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     // ---- 4. deferred shading + finalise (kernels_shade.h; obj/core.py:640)
     const bool lit = (int16_t)sten == 0;                  // the reference's buffer is int16
     if (live) {
+        const TileKernArgs &ka = kernargs<TileKernArgs>();
+        const FrameConst &fc = ka.fc;
+        const TileArgs &ta = ka.ta;
+        const ShadeArgs &sh = ka.sh;
+        const LightConst lc = light_const(fc);
         float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
         bool ready_u8 = false;
         if (best >= 0) {
-            const TriRec t = tris[best];
+            const TriRec t = sh.tris[best];
             const TriAttr &at = sh.attrs[best];
             const Material *mp = mat_lds ? reinterpret_cast<const Material *>(s_mat) + t.material
                                          : sh.materials + t.material;
-            shade_pixel(fc, t, at, *mp, px, py, lit, rgb);
+            shade_pixel(lc, t, at, *mp, px, py, lit, rgb);
         } else if ((fc.flags & MR_FRAME_SKYBOX) && sh.sky) {
             sky_color(fc, sh.sky, px, py, rgb);
         } else if (fc.background_u8 >> 24) {
@@ -698,6 +755,7 @@ k_tile(const FrameConst fc, const TileArgs ta, const ShadeArgs sh)
     __syncthreads();
     // per-tile partial counts, summed by k_reduce_tile_stats (thousands of workgroups adding to
     // one cache line of counters would serialise at the memory side)
+    const TileArgs &ta = kernargs<TileKernArgs>().ta;
     uint32_t *rec = ta.tile_stats + (size_t)tile * TILE_REC;
     if (tid < TILE_STATS) rec[tid] = s_cnt[tid];
     if (tid == 0) {                                       // list lengths; timing for mr_debug_read_tile_records

@@ -581,10 +581,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sh.gamma_lut = sc->d_gamma.as<float>();
     sh.frame = (fc.flags & MR_FRAME_KEEP_FLOAT) ? fs->d_frame.as<float>() : nullptr;
     sh.out = d_out;
+    TileKernArgs tka;
+    tka.fc = fc; tka.ta = ta; tka.sh = sh;
     if (n_tiles > 0 && n_tiles <= 2048)
-        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + SPLIT_FRONT)), dim3(TILE_PX), 0, stream, fc, ta, sh);
+        hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + SPLIT_FRONT)), dim3(TILE_PX), 0, stream, tka);
     else if (n_tiles > 0)
-        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, fc, ta, sh);
+        hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, tka);
     else          // nothing to draw on this device (a stripe beyond the frame): still hand the counters on
         HIP_TRY(hipMemsetAsync(next_ctr, 0, sizeof(Counters), stream));
     if (timing) HIP_TRY(hipEventRecord(fs->ev[4], stream));
