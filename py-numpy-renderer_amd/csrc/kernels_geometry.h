@@ -206,7 +206,11 @@ k_vertex_mfma(const FrameConst fc, const double *__restrict__ verts, VertexOut *
 }
 
 // Survivors of coverage + clip among the samples of a triangle's pixel box, as seen by one lane.
-__device__ __forceinline__ bool sample_survives(const FrameConst &fc, const TriRec &t, const double dp[3],
+// (what the sample tests read of the frame constants, as values: fetched once in front of a loop over samples)
+struct SampleConst { int band_y0, band_y1, same_clip; };
+__device__ __forceinline__ SampleConst sample_const(const FrameConst &fc) { return { fc.band_y0, fc.band_y1, fc.same_clip }; }
+
+__device__ __forceinline__ bool sample_survives(const SampleConst &fc, const TriRec &t, const double dp[3],
                                                 const TriClip *clips, int px, int py, bool &covered_in_band)
 {
     const bool single = (t.flags & TF_SINGLE_BOX) != 0;
@@ -260,13 +264,27 @@ struct SetupArgs {
     uint32_t quad_cap;
 };
 
+// k_setup's arguments in one block, read phase by phase through kernargs<>() (rast_math.h): the three 4x4 matrices,
+// the six planes and two dozen pointers do not fit the scalar registers at once, and read as plain arguments they
+// were all fetched at the top and parked in vector-register lanes.
+struct SetupKernArgs { FrameConst fc; SetupArgs sa; BinArgs bins; uint32_t face_blocks; };
+#define SETUP_ARGS() const SetupKernArgs &ka_ = kernargs<SetupKernArgs>(); const FrameConst &fc = ka_.fc; \
+                     const SetupArgs &sa = ka_.sa; const BinArgs &bins = ka_.bins; (void)fc; (void)sa; (void)bins
+
+struct CornerOut;
+template <bool PRE_XFORM>
+__device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int4 &ib, const int4 &ic, uint8_t ff,
+                                                const double va[4], const double vb[4], const double vc[4],
+                                                const CornerOut &A, const CornerOut &B, const CornerOut &C,
+                                                unsigned int &covered, PrimBox &pb, bool &clip);
+
 // One face: status, TriRec / TriAttr / TriClip.  Returns bit 0 = the face goes on to the tile
 // kernel, bit 1 = its survivor count is left to k_bin_work; `covered` receives the fragments of a
 // face settled as CLIPPED right here.
 template <bool PRE_XFORM>
-__device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const SetupArgs &sa, unsigned int &covered,
-                                             PrimBox &pb, bool &clip)
+__device__ __forceinline__ int tri_setup_one(int f, unsigned int &covered, PrimBox &pb, bool &clip)
 {
+    SETUP_ARGS();                                                // phase 1: index row, corners, transform, cull
     const int4 *row = reinterpret_cast<const int4 *>(sa.faces + (size_t)f * 12);
     const int4 ia = row[0], ib = row[1], ic = row[2];          // [vertex, uv, normal, material] per corner
     const uint8_t ff = sa.face_flags[f];
@@ -307,6 +325,18 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
         if (cull) { status[f] = FACE_BACK_FACE_CULLING; return 0; }
     }
 
+    return tri_setup_record<PRE_XFORM>(f, ia, ib, ic, ff, va, vb, vc, A, B, C, covered, pb, clip);
+}
+
+// second half of tri_setup_one: the faces that survive the cull (its own view of the arguments: phase 2)
+template <bool PRE_XFORM>
+__device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int4 &ib, const int4 &ic, uint8_t ff,
+                                                const double va[4], const double vb[4], const double vc[4],
+                                                const CornerOut &A, const CornerOut &B, const CornerOut &C,
+                                                unsigned int &covered, PrimBox &pb, bool &clip)
+{
+    SETUP_ARGS();
+    uint8_t *status = sa.status;
     TriRec t;
     double xs[3] = { A.sx, B.sx, C.sx }, ys[3] = { A.sy, B.sy, C.sy };
     int bx0, bx1, by0, by1;
@@ -350,10 +380,11 @@ __device__ __forceinline__ int tri_setup_one(const FrameConst &fc, int f, const 
     const double dp[3] = { A.depth, B.depth, C.depth };
     if (count_here) {
         const int bw = bx1 - bx0;
+        const SampleConst sc = sample_const(fc);
         int found = 0;
         for (int idx = 0; idx < (int)box && found < 2; ++idx) {
             bool cov;
-            found += sample_survives(fc, t, dp, nullptr, bx0 + idx % bw, by0 + idx / bw, cov) ? 1 : 0;
+            found += sample_survives(sc, t, dp, nullptr, bx0 + idx % bw, by0 + idx / bw, cov) ? 1 : 0;
             covered += cov ? 1u : 0u;
         }
         if (found == 0) {
@@ -404,7 +435,7 @@ constexpr int SETUP_BLOCK = 256;
 // Face workgroup: one face per lane.  The list of faces whose survivor count needs a wavefront and
 // the frame's count of set-up faces are appended to with ONE atomic per workgroup.
 template <bool PRE_XFORM>
-__device__ __forceinline__ void tri_setup_block(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins, uint32_t block)
+__device__ __forceinline__ void tri_setup_block(uint32_t block)
 {
     constexpr int NW = SETUP_BLOCK / WAVE;
     __shared__ uint32_t s_valid[NW], s_count[NW], s_covered;
@@ -414,7 +445,8 @@ __device__ __forceinline__ void tri_setup_block(const FrameConst &fc, const Setu
     unsigned int covered = 0;
     PrimBox pb = { 0, 0, 0, 0 };
     bool clip = false;
-    const int r = f < fc.n_faces ? tri_setup_one<PRE_XFORM>(fc, f, sa, covered, pb, clip) : 0;
+    const int r = f < kernargs<SetupKernArgs>().fc.n_faces ? tri_setup_one<PRE_XFORM>(f, covered, pb, clip) : 0;
+    SETUP_ARGS();                                                // phase 3: the tile lists, the workgroup's epilogue
     // the face's own tile lists (kernels_bin.h)
     bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);
     const unsigned long long bv = __ballot(r & 1), bc = __ballot(r & 2);
@@ -453,6 +485,7 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t n_count = ctr->n_count;
     const uint32_t waves = n_blocks * (blockDim.x / WAVE);
+    const SampleConst sc = sample_const(fc);
     for (uint32_t i = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; i < n_count; i += waves) {
         const int fb = (int)count_list[i];
         const TriRec tb = tris[fb];
@@ -467,7 +500,7 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
         for (long long c = 0; c < chunks && found < 2; ++c) {
             const long long idx = ((first + c) % chunks) * WAVE + lane;
             bool cov = false, ok = false;
-            if (idx < n) ok = sample_survives(fc, tb, dp, clips, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w), cov);
+            if (idx < n) ok = sample_survives(sc, tb, dp, clips, tb.x0 + (int)(idx % w), tb.y0 + (int)(idx / w), cov);
             found += __popcll(__ballot(ok));
         }
         if (lane == 0) count_finish(tris, status, fb, tb.flags, found);
@@ -484,7 +517,7 @@ __device__ __forceinline__ bool sample_is_drawn(const FrameConst &fc, const TriR
                                                 int px, int py)
 {
     bool cov;
-    if (!sample_survives(fc, t, dp, clips, px, py, cov)) return false;
+    if (!sample_survives(sample_const(fc), t, dp, clips, px, py, cov)) return false;
     float u, v, w;
     tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
     const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
@@ -558,8 +591,7 @@ __device__ __forceinline__ double shfl_d(double v, int src)
 constexpr int QS_LANES = 16;
 static_assert(MAX_POLY <= QS_LANES, "one polygon vertex per lane");
 
-__device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins,
-                                                 bool have, int sil_f, int sil_k, uint32_t s_base_raw, uint32_t s_rank,
+__device__ __forceinline__ void quad_setup_group(bool have, int sil_f, int sil_k, uint32_t s_base_raw, uint32_t s_rank,
                                                  double (*s_poly)[MAX_POLY + 4][4])
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -568,6 +600,8 @@ __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const Set
     // ---- extrusion (obj/core.py:612-621): quad = (A, B, D, C); lanes 0..3 hold A, B, D, C
     double v[4] = { 0, 0, 0, 0 };
     int n = have ? 4 : 0;
+    {
+    SETUP_ARGS();                                                // phase: the edge's corners, extrusion
     if (have && gl < 4) {
         const int32_t *fcx = sa.faces + (size_t)sil_f * 12;
         const int ia = fcx[sil_k * 4], ib = fcx[((sil_k + 1) % 3) * 4];
@@ -585,8 +619,11 @@ __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const Set
             }
         }
     }
+    }
 
     // ---- clipping, one plane at a time
+    {
+    const FrameConst &fc = kernargs<SetupKernArgs>().fc;         // phase: the six planes
     for (int pl = 0; pl < 6; ++pl) {
         const double *P = fc.planes + pl * 4;
         const bool mine = gl < n;
@@ -638,7 +675,9 @@ __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const Set
             if (gl < n) for (int j = 0; j < 4; ++j) v[j] = s_poly[grp][gl][j];
         }
     }
+    }
     const bool alive = n >= 3;                           // obj/triangular.py:322-323
+    SETUP_ARGS();                                                // phase: projection, box, record
 
     // ---- projection of the lane's vertex (obj/triangular.py:325-327)
     double sx = 0, sy = 0, sz = 0;
@@ -715,8 +754,9 @@ __device__ __forceinline__ void quad_setup_group(const FrameConst &fc, const Set
 // mesh runs along consecutive vertex indices, and without that a wavefront would find dozens
 // of silhouette edges among its 64 and set their quads up four at a time while the rest of the
 // device idles.
-__device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs &sa, const BinArgs &bins, uint32_t block)
+__device__ __forceinline__ void edge_block(uint32_t block)
 {
+    SETUP_ARGS();
     __shared__ double s_poly[SETUP_BLOCK / WAVE][WAVE / QS_LANES][MAX_POLY + 4][4];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
     const int e = (int)(block * blockDim.x + threadIdx.x);
@@ -771,25 +811,34 @@ __device__ __forceinline__ void edge_block(const FrameConst &fc, const SetupArgs
         const bool have = src >= 0;
         const uint32_t ls = (uint32_t)__shfl((int)last, have ? src : 0);
         const uint32_t rank = (uint32_t)__shfl((int)my_rank, have ? src : 0);
-        quad_setup_group(fc, sa, bins, have, (int)(ls >> 2), (int)(ls & 3u), base_raw, rank, s_poly[wv]);
+        quad_setup_group(have, (int)(ls >> 2), (int)(ls & 3u), base_raw, rank, s_poly[wv]);
     }
     const uint32_t my_slot = (uint32_t)__shfl((int)base_raw, 0) + my_rank;
-    if (sil && my_slot < sa.quad_cap) {
-        sa.sil_edges[my_slot * 2 + 0] = (int32_t)(last >> 2);       // the host maps the face back to its model
-        sa.sil_edges[my_slot * 2 + 1] = (int32_t)(last & 3u);
+    const SetupArgs &sa2 = kernargs<SetupKernArgs>().sa;
+    if (sil && my_slot < sa2.quad_cap) {
+        sa2.sil_edges[my_slot * 2 + 0] = (int32_t)(last >> 2);      // the host maps the face back to its model
+        sa2.sil_edges[my_slot * 2 + 1] = (int32_t)(last & 3u);
     }
 }
 
 // First launch of the frame: workgroup 0 puts the frame's tiles in order (a serial walk of some microseconds,
 // hidden behind the others), workgroups [1, 1 + face_blocks) set faces up, the rest look at edges.
+#ifndef MR_SETUP_WAVES
+#define MR_SETUP_WAVES 4
+#endif
 template <bool PRE_XFORM>
-__global__ void __launch_bounds__(SETUP_BLOCK, 4)
-k_setup(const FrameConst fc, const SetupArgs sa, const BinArgs bins, uint32_t face_blocks)
+__global__ void __launch_bounds__(SETUP_BLOCK, MR_SETUP_WAVES)
+k_setup(const SetupKernArgs)            // read through kernargs<SetupKernArgs>(), phase by phase
 {
-    if (blockIdx.x == 0) { order_tiles_block(sa.tile_class, sa.order, fc.tiles_x * fc.tiles_y); return; }
+    uint32_t face_blocks;
+    {
+        const SetupKernArgs &ka = kernargs<SetupKernArgs>();
+        if (blockIdx.x == 0) { order_tiles_block(ka.sa.tile_class, ka.sa.order, ka.fc.tiles_x * ka.fc.tiles_y); return; }
+        face_blocks = ka.face_blocks;
+    }
     const uint32_t b = blockIdx.x - 1;
-    if (b < face_blocks) tri_setup_block<PRE_XFORM>(fc, sa, bins, b);
-    else edge_block(fc, sa, bins, b - face_blocks);
+    if (b < face_blocks) tri_setup_block<PRE_XFORM>(b);
+    else edge_block(b - face_blocks);
 }
 
 // Second launch: the leftover survivor counts (a few workgroups, first so that their

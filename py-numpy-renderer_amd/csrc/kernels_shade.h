@@ -181,33 +181,14 @@ __device__ __forceinline__ void shade_pixel(const LightConst &fc, const TriRec &
     const double tu = gemv3(p[0], p[1], p[2], (double)at.uv[0][0], (double)at.uv[1][0], (double)at.uv[2][0]);
     const double tv = gemv3(p[0], p[1], p[2], (double)at.uv[0][1], (double)at.uv[1][1], (double)at.uv[2][1]);
 
-    double color[3];
-    if (mat.map_kd.rgb) {
-        const float *tx = texel(mat.map_kd, tu, tv);
-        color[0] = tx[0]; color[1] = tx[1]; color[2] = tx[2];
-    } else {
-        color[0] = mat.kd[0]; color[1] = mat.kd[1]; color[2] = mat.kd[2];
-    }
-    const double *wa = at.world[0], *wb = at.world[1], *wc = at.world[2];
-    double pos[3], dl[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        pos[j] = chain3(p[0], p[1], p[2], wa[j], wb[j], wc[j]);
-        dl[j] = fc.light_pos[j] - pos[j];
-    }
-    // Light.attenuation (obj/core.py:517-524)
-    const double dl2 = (dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2];
-    const double dist = dl2 > 0 ? dl2 * c_rsqrt(dl2) : 0.0;
-    const double att = c_rcp(fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
-
-    if (!lit) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) rgb[j] = (float)clip01((att * fc.light_ambient[j]) * color[j]);
-        return;
-    }
-    // ---- Face.get_normals / tangent_ (obj/core.py:175-224)
-    double raw[3], interp[3] = { 0, 0, 0 };
+    // ---- Face.get_normals / tangent_ (obj/core.py:175-224), FIRST: it is the part with the most values in flight
+    // (two edge vectors, two cross products, the uv deltas: ~50 registers of float64), and with the colour, the
+    // position and the light vector already waiting in registers beside it the pixel did not fit the 80 registers
+    // of six wavefronts per SIMD.  Only lit pixels need the normal.
+    double raw[3] = { 0, 0, 0 }, interp[3] = { 0, 0, 0 };
     bool raw_is_unit = false;
+    const double *wa = at.world[0], *wb = at.world[1], *wc = at.world[2];
+    if (lit) {
     const bool has_n = (ff & FF_HAS_NORMALS) != 0;
     if (has_n) {
 #pragma unroll
@@ -281,6 +262,30 @@ __device__ __forceinline__ void shade_pixel(const LightConst &fc, const TriRec &
             c_normalize3(cr, fn);
         }
         for (int j = 0; j < 3; ++j) raw[j] = chain3(p[0], p[1], p[2], fn[j], fn[j], fn[j]);
+    }
+    }
+    double color[3];
+    if (mat.map_kd.rgb) {
+        const float *tx = texel(mat.map_kd, tu, tv);
+        color[0] = tx[0]; color[1] = tx[1]; color[2] = tx[2];
+    } else {
+        color[0] = mat.kd[0]; color[1] = mat.kd[1]; color[2] = mat.kd[2];
+    }
+    double pos[3], dl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        pos[j] = chain3(p[0], p[1], p[2], wa[j], wb[j], wc[j]);
+        dl[j] = fc.light_pos[j] - pos[j];
+    }
+    // Light.attenuation (obj/core.py:517-524)
+    const double dl2 = (dl[0] * dl[0] + dl[1] * dl[1]) + dl[2] * dl[2];
+    const double dist = dl2 > 0 ? dl2 * c_rsqrt(dl2) : 0.0;
+    const double att = c_rcp(fc.att_constant + dist * (fc.att_linear + fc.att_quadratic * dist));
+
+    if (!lit) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rgb[j] = (float)clip01((att * fc.light_ambient[j]) * color[j]);
+        return;
     }
     double N[3], L[3], V[3], Hh[3], tmp[3];
     if (raw_is_unit) { N[0] = raw[0]; N[1] = raw[1]; N[2] = raw[2]; }

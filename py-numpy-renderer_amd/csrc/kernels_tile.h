@@ -152,8 +152,8 @@ static_assert(sizeof(Material) % 8 == 0 && MAT_LDS * sizeof(Material) / 8 <= TIL
 // cost thresholds of classes 1..7 (tile_cost units, ~0.1 us); the rest is class 8
 __device__ __forceinline__ int tile_class(uint32_t cost)
 {
-    return cost >= 900u ? 1 : cost >= 600u ? 2 : cost >= 400u ? 3 : cost >= 250u ? 4 : cost >= 150u ? 5 : cost >= 90u ? 6
-         : cost >= 45u ? 7 : 8;
+    return cost >= 500u ? 1 : cost >= 350u ? 2 : cost >= 250u ? 3 : cost >= 170u ? 4 : cost >= 110u ? 5 : cost >= 70u ? 6
+         : cost >= 40u ? 7 : 8;
 }
 static_assert(ORDER_CLASSES == 8, "tile_class");
 // On a device that owns few tiles (a rank of a multi-GPU split: all its tiles are resident at once and
@@ -165,7 +165,10 @@ static_assert(ORDER_CLASSES == 8, "tile_class");
 // counter, no waiting) adds the others' and shades.  Only frames rendered for the frame's sake are split
 // (no MR_FRAME_COUNTERS), and only in the k_tile<true> instantiation: on a device that owns the whole
 // frame the launch is bound by the tiles' total work, which the repeated rasterisation only adds to
-// (measured on MI355X, c4: 86 -> 90 us whole frame; a rank of 8: 56 -> 38 us).
+// (measured on MI355X in round 2, c4: 86 -> 90 us whole frame; a rank of 8: 56 -> 38 us).  Round 3: with the
+// heaviest tiles started first a whole frame's launch lasts exactly as long as its single heaviest tile (c4:
+// 63.7 of 64.4 us, 46 of them its 111 shadow quads), so a lone whole frame now shares out its few heaviest tiles
+// too -- a dozen on c4, chosen by a higher threshold (TileArgs::split_cost / split_quads) -- and nothing else.
 constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = 128;
 #ifndef MR_TILE_WAVES
 #define MR_TILE_WAVES 5
@@ -173,10 +176,11 @@ constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = 128;
 constexpr int K_TILE_WAVES = MR_TILE_WAVES;              // wavefronts per SIMD the tile kernel's register budget allows
 constexpr int SPLIT_FRONT = HEAVY_SPLIT * HEAVY0_MAX;     // extra workgroups of a k_tile<true> launch
 
-// estimated cost of a tile in ~0.1 us from its list lengths (fitted to measured tile times on MI355X)
+// estimated cost of a tile in ~0.1 us from its list lengths: the least-squares fit of the measured tile times of
+// c4 on MI355X with six wavefronts per SIMD, 20.1 + 1.63 small + 29.8 big + 3.19 quads (tools/diag_tiles.py), rounded
 __device__ __forceinline__ uint32_t tile_cost(uint32_t n_small, uint32_t n_big, uint32_t n_quad)
 {
-    return 30u + 3u * n_small + 15u * n_big + 6u * n_quad;
+    return 20u + 2u * n_small + 30u * n_big + 3u * n_quad;
 }
 
 struct TileArgs {
@@ -194,24 +198,10 @@ struct TileArgs {
     uint32_t *split_arrive;       // [HEAVY0_MAX] parts that have left theirs (zero between frames)
     const uint32_t *order;        // ORDER_HEAD words, then the tiles in the order to render them (k_bin_work); null: row-major
     uint8_t *tile_class;          // [n_tiles] what this frame leaves for the next: 1 + the tile's cost class
+    uint32_t split_cost, split_quads;   // k_tile<true>: a tile this costly, with this many shadow quads, is shared out next frame
 };
 
 struct TileKernArgs { FrameConst fc; TileArgs ta; ShadeArgs sh; };
-
-// The kernel's arguments as ONE PHASE of the kernel sees them: a reference into the kernarg segment through a
-// pointer the compiler cannot see through, so the scalar loads of what a phase uses are issued in that phase and
-// their registers are dead after it.  Read as plain by-value arguments, the ~1 KB of frame constants and 25
-// pointers were all fetched at the top of the kernel and kept for its whole length: 106 SGPRs, and beyond those
-// the compiler parked them in lanes of two VGPRs -- ~110 v_writelane at the head of every wavefront and up to
-// 390 v_readlane along it, a fifth of the vector instructions k_tile issued (rocprofv3 SQ_INSTS_VALU).
-template <class T>
-__device__ __forceinline__ const T &kernargs()
-{
-    typedef const __attribute__((address_space(4))) char *kernarg_ptr;
-    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *(const T *)(const char *)p;
-}
 
 // One workgroup per tile, one pixel per thread.  Tiles are dealt to workgroups in plain
 // row-major order, i.e. round-robin over the XCDs: heavy tiles cluster on the screen, and an
@@ -233,7 +223,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
     const int lp = tid;                                   // pixel of this thread inside the tile
 
     // ---- 0. which tile, and what it lists
-    int tile = 0, part = 0, n_parts = 1, entry = 0, n_tiles, ltr, gx, gy, px, py;
+    int tile = 0, part = 0, n_parts = 1, entry = 0, n_tiles, ltr, gx, gy;
     bool rh, counters, live, mat_lds;
     uint32_t n_small_raw, n_big_raw, n_quad_raw, n_small, n_big, n_quad, cost;
     unsigned long long t_start;
@@ -281,7 +271,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         tile = ta.order ? (int)ta.order[ORDER_HEAD + idx] : (int)idx;
         ltr = tile / fc.tiles_x;                          // local tile row
         gx = (tile % fc.tiles_x) * TILE_W; gy = tile_row_frame(fc, ltr) * TILE_H;
-        px = gx + (lp & (TILE_W - 1)); py = gy + lp / TILE_W;
+        const int px = gx + (lp & (TILE_W - 1)), py = gy + lp / TILE_W;
         live = px < fc.width && py >= fc.band_y0 && py < fc.band_y1;
         t_start = __builtin_amdgcn_s_memrealtime();
 
@@ -291,8 +281,8 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         // the heaviest tiles are the frame's critical path: their wavefronts go first wherever they
         // compete with a lighter tile's for a SIMD's issue slots
         cost = tile_cost(n_small_raw, n_big_raw, n_quad_raw);
-        if (cost >= 900u) __builtin_amdgcn_s_setprio(3);
-        else if (cost >= 400u) __builtin_amdgcn_s_setprio(1);
+        if (cost >= 500u) __builtin_amdgcn_s_setprio(3);
+        else if (cost >= 250u) __builtin_amdgcn_s_setprio(1);
 
         // Nothing listed for this tile (a third of a typical frame): its pixels show the background, which
         // the host has finalised already, or the skybox (no lists to walk, no barriers but the gamma table's).
@@ -333,7 +323,15 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         if (mat_lds && tid < fc.n_materials * (int)(sizeof(Material) / 8))
             s_mat[tid] = reinterpret_cast<const unsigned long long *>(sh.materials)[tid];
     }
-    const double dpx = (double)px, dpy = (double)py;
+    // The pixel's coordinates are recomputed from the thread index where a phase needs them (two instructions),
+    // from a copy of the index the compiler cannot connect to the other phases': kept in registers from the first
+    // phase to the last, px, py and their float64 images held six of the 80 registers a wavefront may use when
+    // six share a SIMD.
+    auto my_pixel = [&](int &px, int &py) {
+        int l = lp;
+        asm volatile("" : "+v"(l));
+        px = gx + (l & (TILE_W - 1)); py = gy + l / TILE_W;
+    };
 
     // ---- 1. big pairs, one pixel per thread (obj/triangular.py:72-118)
     double zbest = rh ? INFINITY : -INFINITY;
@@ -352,6 +350,9 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         const uint32_t *__restrict__ big_items = ta.items[1] + (size_t)tile * ta.cap[1];
         const bool same_clip = fc.same_clip != 0, has_no_depth = fc.has_no_depth != 0;
         const TileBounds tb = { fc.width, fc.band_y0, fc.band_y1 };
+        int px, py;
+        my_pixel(px, py);
+        const double dpx = (double)px, dpy = (double)py;
         unsigned int frags = 0;
         // The records of up to 64 pairs are copied to LDS once per workgroup, 16 bytes per lane and step
         // (the staging area of the shadow quads, not in use yet), and every lane then reads the pair it is
@@ -497,6 +498,9 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         const uint32_t *__restrict__ quad_items = ta.items[2] + (size_t)tile * ta.cap[2];
         const QuadRec *__restrict__ quads = ta.quads;
         const double f_plus_n = fc.f_plus_n, f_minus_n = fc.f_minus_n, two_nf = fc.two_nf;     // fetched once, see above
+        int px, py;
+        my_pixel(px, py);
+        const double dpx = (double)px, dpy = (double)py;
         // most and least favourable covered z of this wavefront's strip (see the depth verdicts below)
         double zlim = rh ? -INFINITY : INFINITY, zhard = rh ? INFINITY : -INFINITY;
         if (covered) zlim = zhard = zbest;
@@ -713,6 +717,8 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         const TileArgs &ta = ka.ta;
         const ShadeArgs &sh = ka.sh;
         const LightConst lc = light_const(fc);
+        int px, py;
+        my_pixel(px, py);
         float rgb[3] = { fc.background[0], fc.background[1], fc.background[2] };
         bool ready_u8 = false;
         if (best >= 0) {
@@ -771,7 +777,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
     if (tid == 0) {                                       // what the slot's next frame should know about this tile
         int cls = tile_class(cost);
         // where tiles are split, class 1 holds those whose quad walk is worth sharing
-        if (SPLIT) cls = (cost >= 600u && n_quad_raw >= 32u) ? 1 : cls < 2 ? 2 : cls;
+        if (SPLIT) cls = (cost >= ta.split_cost && n_quad_raw >= ta.split_quads) ? 1 : cls < 2 ? 2 : cls;
         ta.tile_class[tile] = (uint8_t)cls;
     }
 }

@@ -524,10 +524,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     {
         const unsigned face_blocks = fc.n_faces > 0 ? blocks_for(fc.n_faces, SETUP_BLOCK) : 0u;
         const unsigned edge_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, SETUP_BLOCK) : 0u;
+        SetupKernArgs ska;
+        ska.fc = fc; ska.sa = sa; ska.bins = ba; ska.face_blocks = face_blocks;
         if (vertex_mfma)
-            hipLaunchKernelGGL(k_setup<true>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
+            hipLaunchKernelGGL(k_setup<true>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, ska);
         else
-            hipLaunchKernelGGL(k_setup<false>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, fc, sa, ba, face_blocks);
+            hipLaunchKernelGGL(k_setup<false>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, ska);
     }
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[2], stream));
 
@@ -583,7 +585,17 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sh.out = d_out;
     TileKernArgs tka;
     tka.fc = fc; tka.ta = ta; tka.sh = sh;
-    if (n_tiles > 0 && n_tiles <= 2048)
+    // which tiles are shared out over HEAVY_SPLIT workgroups next frame: on a device whose tiles are all resident
+    // at once every tile with a quad walk worth sharing; on a whole frame only the handful that outlast
+    // everything else (the launch then ends with them).  MR_TILE_SPLIT=0 | 1 forces it off / on for every grid.
+    static const int split_mode = [] { const char *e = getenv("MR_TILE_SPLIT"); return !e ? -1 : atoi(e); }();
+    const bool small_grid = n_tiles <= 2048;
+    static const unsigned split_cost_big = [] { const char *e = getenv("MR_SPLIT_COST"); return e ? (unsigned)atoi(e) : 400u; }();
+    static const unsigned split_quads_big = [] { const char *e = getenv("MR_SPLIT_QUADS"); return e ? (unsigned)atoi(e) : 48u; }();
+    tka.ta.split_cost = small_grid ? 350u : split_cost_big;
+    tka.ta.split_quads = small_grid ? 32u : split_quads_big;
+    const bool split = split_mode < 0 ? (small_grid || ordered) : split_mode != 0;
+    if (n_tiles > 0 && split)
         hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + SPLIT_FRONT)), dim3(TILE_PX), 0, stream, tka);
     else if (n_tiles > 0)
         hipLaunchKernelGGL(k_tile<false>, dim3((unsigned)n_tiles), dim3(TILE_PX), 0, stream, tka);

@@ -14,6 +14,21 @@
 
 namespace mr {
 
+// The kernel's arguments as ONE PHASE of the kernel sees them: a reference into the kernarg segment through a
+// pointer the compiler cannot see through, so the scalar loads of what a phase uses are issued in that phase and
+// their registers are dead after it.  Read as plain by-value arguments, the ~1 KB of frame constants and 25
+// pointers were all fetched at the top of the kernel and kept for its whole length: 106 SGPRs, and beyond those
+// the compiler parked them in lanes of two VGPRs -- ~110 v_writelane at the head of every wavefront and up to
+// 390 v_readlane along it, a fifth of the vector instructions k_tile issued (rocprofv3 SQ_INSTS_VALU).
+template <class T>
+__device__ __forceinline__ const T &kernargs()
+{
+    typedef const __attribute__((address_space(4))) char *kernarg_ptr;
+    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T *)(const char *)p;
+}
+
 // 1-D dot and GEMM (M,K)@(K,P>=2): ascending k, first term a rounded product.
 __device__ __forceinline__ double chain2(double a0, double a1, double b0, double b1)
 {
