@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MR_ABI_VERSION 2
+#define MR_ABI_VERSION 3
 
 enum {
     MR_OK = 0,
@@ -195,25 +195,44 @@ int mr_scene_set_list_capacities(mr_scene *scene, uint32_t small_pairs, uint32_t
  * statement lists.  The host walks the frustum's edges (float64 DDA) segment by segment; every kept point
  * of a segment performs the reference's writes in the reference's order: centre (z and red), then for step
  * -1 and +1: z into the row neighbour, z into the column neighbour, half blend into the row neighbour, half
- * blend into the column neighbour.  target / next are (5, n_points) row-major: per target set (centre,
- * row-1, col-1, row+1, col+1) the linear pixel index row * width + col (row = screen y, not flipped) and
- * the index of the next point OF THE SAME SEGMENT with the same target (-1: none; NumPy's "last one wins").
- * touched lists every pixel any statement writes, once.  Pointers are read during the call only.
- * NULL (or n_points == 0) removes the overlay.  Frames that set MR_FRAME_OVERLAY replay it. */
+ * blend into the column neighbour.  target is (5, n_points) row-major: per target set (centre, row-1, col-1,
+ * row+1, col+1) the linear pixel index row * width + col (row = screen y, not flipped) in a frame of height x
+ * width; segments follow each other in drawing order and cover the point array.  The device replays the segments
+ * in order (csrc/kernels_overlay.h).  Pointers are read during the call only.  NULL (or n_points == 0) removes the overlay.  Frames that set
+ * MR_FRAME_OVERLAY replay it; the frame must have the size named here. */
 typedef struct mr_overlay_desc {
-    int32_t n_segments, n_points, n_touched, reserved;
+    int32_t n_segments, n_points, height, width;
     const int32_t *seg_first, *seg_count;   /* (n_segments) first point and number of points of each segment */
     const int32_t *target;                  /* (5, n_points) */
-    const int32_t *next;                    /* (5, n_points) */
     const double *z;                        /* (n_points) linearised depth of each point */
-    const int32_t *touched;                 /* (n_touched) */
 } mr_overlay_desc;
 int mr_scene_set_overlay(mr_scene *scene, const mr_overlay_desc *overlay);
+
+/* The same overlay straight from the two cameras, everything on the host side of the library in one call
+ * (replaces obj/frustums.py:61-103 + obj/line.py:6-16: clipping, projection, DDA, dashes, index wrapping; the
+ * upload is one asynchronous copy in front of the next frame that draws the overlay): the frustum's eight corners
+ * (8 x 4, already divided by w: CUBE @ inv(debug MVP), obj/frustums.py:52-53), the viewing camera's six planes
+ * (6 x 4), its MVP and viewport (4 x 4, row vectors), near / far, whether the viewing camera sits inside the
+ * frustum (obj/frustums.py:57-60), and the frame's size. */
+int mr_scene_set_overlay_cameras(mr_scene *scene, const double *corners, const double *planes, const double *mvp,
+                                 const double *viewport, double near_plane, double far_plane, int32_t camera_inside,
+                                 int32_t height, int32_t width);
 
 /* Scene.render() -- obj/core.py:587-640: depth/ambient pass, shadow-volume stencil pass, lit
  * pass and finalise (flip, **0.8, *255, uint8) on the GPU.  out_rgb receives
  * (row_end - row_begin) x width x 3 bytes, row 0 = top row of the band.  stats may be NULL. */
 int mr_render(mr_scene *scene, const mr_frame_desc *frame, uint8_t *out_rgb, mr_stats *stats);
+
+/* mr_render in two halves, for frames of a sequence: mr_render_async enqueues the frame and the device-to-host copy
+ * of its uint8 rows into out_rgb on one of the scene's MR_ASYNC_LANES lanes (a stream and a set of work buffers
+ * each) and returns at once; mr_render_wait blocks until that lane's frame is in out_rgb.  With two lanes the copy
+ * of frame i (6 MB at 1080p: longer than the frame's kernels) runs beside the kernels of frame i + 1 and beside the
+ * host's preparation of frame i + 2.  out_rgb should be page-locked (mr_host_alloc) for the copy to be
+ * asynchronous at all.  A frame that overflowed a work list is reported by mr_render_wait as MR_E_OVERFLOW (the
+ * lists have been grown): render it again.  stats may be NULL. */
+#define MR_ASYNC_LANES 4
+int mr_render_async(mr_scene *scene, const mr_frame_desc *frame, uint8_t *out_rgb, int32_t lane);
+int mr_render_wait(mr_scene *scene, int32_t lane, mr_stats *stats);
 
 /* Page-locked host memory for mr_render's out_rgb (hipHostMalloc / hipHostFree): the device-to-host copy
  * of the frame then runs at the full PCIe rate instead of being staged through the runtime's own buffers.

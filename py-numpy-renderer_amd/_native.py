@@ -23,7 +23,7 @@ FRAME_SHADOWS, FRAME_KEEP_FLOAT, FRAME_FACE_STATUS, FRAME_LIGHT_TIMING, FRAME_SK
 FRAME_KEEP_BUFFERS = 64
 FRAME_NO_TIMING = 128
 FRAME_OVERLAY = 256
-ABI_VERSION = 2
+ABI_VERSION = 3
 TILE_RECORD_WORDS = 12
 
 
@@ -57,9 +57,8 @@ class ModelDesc(C.Structure):
 
 
 class OverlayDesc(C.Structure):
-    _fields_ = [("n_segments", C.c_int32), ("n_points", C.c_int32), ("n_touched", C.c_int32), ("reserved", C.c_int32),
-                ("seg_first", C.c_void_p), ("seg_count", C.c_void_p), ("target", C.c_void_p), ("next", C.c_void_p),
-                ("z", C.c_void_p), ("touched", C.c_void_p)]
+    _fields_ = [("n_segments", C.c_int32), ("n_points", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("seg_first", C.c_void_p), ("seg_count", C.c_void_p), ("target", C.c_void_p), ("z", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -85,8 +84,12 @@ _PROTOTYPES = {
     "mr_scene_add_model": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc)]),
     "mr_scene_clear": (C.c_int, [C.c_void_p]),
     "mr_scene_set_overlay": (C.c_int, [C.c_void_p, C.POINTER(OverlayDesc)]),
+    "mr_scene_set_overlay_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                               C.c_int32, C.c_int32, C.c_int32]),
     "mr_scene_set_list_capacities": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "mr_render_async": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int32]),
+    "mr_render_wait": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     "mr_host_alloc": (C.c_void_p, [C.c_uint64]),
     "mr_host_free": (None, [C.c_void_p]),
     "mr_render_device": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p]),
@@ -326,21 +329,35 @@ class DeviceRenderer:
         dbg = scene.debug_camera if scene.debug_camera is not None else cam
         key = (id(cam), id(dbg), id(cam.__dict__.get("MVP")), id(dbg.__dict__.get("MVP")), tuple(scene.resolution),
                int(scene.system), int(scene.subsystem))
-        if getattr(self, "_overlay_key", None) == key:
+        if getattr(self, "_overlay_key", None) == key or getattr(self, "_overlay_pinned", False):
             return
         # the key holds ids: keep the objects alive while it is cached, so that no other camera or matrix can
         # be given a recycled address and pass for them
-        from .frustums import OverlayOps
-        ops = OverlayOps(cam, dbg, scene.resolution)
-        d = OverlayDesc()
-        d.n_segments, d.n_points, d.n_touched = len(ops.seg_first), ops.n_points, len(ops.touched)
-        d.seg_first, d.seg_count = ops.seg_first.ctypes.data, ops.seg_count.ctypes.data
-        d.target, d.next, d.z, d.touched = (ops.target.ctypes.data, ops.next.ctypes.data, ops.z.ctypes.data,
-                                            ops.touched.ctypes.data)
-        _check(self.lib.mr_scene_set_overlay(self.handle, C.byref(d) if ops.n_points else None), "mr_scene_set_overlay")
+        from .frustums import frustum_corners
+        # the two inverses / vector products of the recipe stay with NumPy (obj/frustums.py:52-60); everything after
+        # them -- clipping, projection, DDA, dashes, the per-pixel lists and their upload -- is one call into the library
+        corners, inside = frustum_corners(cam, dbg)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        corners, planes, mvp, viewport = f64(corners), f64(cam.frustum_planes), f64(cam.MVP), f64(cam.viewport)
+        height, width = (int(v) for v in scene.resolution)
+        _check(self.lib.mr_scene_set_overlay_cameras(self.handle, corners.ctypes.data, planes.ctypes.data, mvp.ctypes.data,
+                                                     viewport.ctypes.data, float(cam.near), float(cam.far), int(inside),
+                                                     height, width), "mr_scene_set_overlay_cameras")
         self._overlay_key = (id(cam), id(dbg), id(cam.__dict__.get("MVP")), id(dbg.__dict__.get("MVP")),
                              tuple(scene.resolution), int(scene.system), int(scene.subsystem))
         self._overlay_refs = (cam, dbg, cam.__dict__.get("MVP"), dbg.__dict__.get("MVP"))
+
+    def set_overlay_lists(self, ops, pin=True):
+        """``mr_scene_set_overlay`` with explicit statement lists (a ``frustums.OverlayOps``); ``sync_overlay`` builds
+        the same inside the library.  While *pin*ned, frames drawn with the overlay keep these lists instead of
+        rebuilding them from the scene's cameras (``pin=False`` hands the overlay back to the cameras)."""
+        d = OverlayDesc()
+        d.n_segments, d.n_points, d.height, d.width = len(ops.seg_first), ops.n_points, ops.height, ops.width
+        d.seg_first, d.seg_count = ops.seg_first.ctypes.data, ops.seg_count.ctypes.data
+        d.target, d.z = ops.target.ctypes.data, ops.z.ctypes.data
+        _check(self.lib.mr_scene_set_overlay(self.handle, C.byref(d) if ops.n_points else None), "mr_scene_set_overlay")
+        self._overlay_key = None
+        self._overlay_pinned = ops is not None and pin
 
     # -- frames ---------------------------------------------------------------------------
     @staticmethod
@@ -391,6 +408,17 @@ class DeviceRenderer:
         microseconds between two kernels; ``last_stats['gpu_ms_*']`` are then 0.
         ``overlay=True`` (``MR_FRAME_OVERLAY``) draws the debug camera's frustum into the frame on the
         device, as the reference's ``render()`` always does (obj/core.py:638)."""
+        desc, out = self._prepare(scene, shadows, row_band, keep_float, face_status, counters, keep_buffers, stripe, timing, overlay)
+        stats = Stats()
+        _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats) if counters else None),
+               "mr_render")
+        # a frame rendered for the frame's sake fetches its statistics only if somebody looks at them
+        self._last_stats = stats.as_dict() if counters else None
+        return out
+
+    def _prepare(self, scene, shadows, row_band, keep_float, face_status, counters, keep_buffers, stripe, timing, overlay):
+        """Everything ``render`` / ``render_async`` do before the library call: scene, skybox and overlay in step
+        with the Python objects, the frame descriptor, a page-locked output array."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = self.packed_frame(scene, shadows)
@@ -408,14 +436,27 @@ class DeviceRenderer:
         desc = self._desc_cached
         self._n_faces = sum(len(m._faces) for m in scene.models)
         rows = desc.row_end - desc.row_begin if stripe is None else stripe_out_rows(pf.height, stripe[1])
-        out = self._pinned.array((rows, pf.width, 3))
-        stats = Stats()
-        _check(self.lib.mr_render(self.handle, C.byref(desc), out.ctypes.data, C.byref(stats) if counters else None),
-               "mr_render")
-        # a frame rendered for the frame's sake fetches its statistics only if somebody looks at them
-        self._last_stats = stats.as_dict() if counters else None
         self._frame = (pf.height, pf.width)
+        return desc, self._pinned.array((rows, pf.width, 3))
+
+    ASYNC_LANES = 4
+
+    def render_async(self, scene, lane, shadows=True, overlay=False):
+        """``mr_render_async``: the frame-only render of ``Scene.render`` enqueued on *lane*; returns the (page-locked)
+        array the frame will land in.  ``render_wait(lane)`` blocks until it has."""
+        desc, out = self._prepare(scene, shadows, None, False, False, False, False, None, False, overlay)
+        _check(self.lib.mr_render_async(self.handle, C.byref(desc), out.ctypes.data, int(lane)), "mr_render_async")
+        self._last_stats = None
         return out
+
+    def render_wait(self, lane):
+        """True when the lane's frame is complete in its array; False when it overflowed a work list (the lists
+        have been grown: render the frame again)."""
+        rc = self.lib.mr_render_wait(self.handle, int(lane), None)
+        if rc == MR_E_OVERFLOW:
+            return False
+        _check(rc, "mr_render_wait")
+        return True
 
     @property
     def last_stats(self):

@@ -336,6 +336,29 @@ def _gizmo(value):
     return sub
 
 
+class PendingFrame:
+    """A frame enqueued by ``Scene.render_async``: ``result()`` waits for it and returns the ``uint8 (H, W, 3)`` array."""
+
+    def __init__(self, scene, lane, out, shadows, cameras):
+        self._scene, self._lane, self._out, self._shadows, self._cameras = scene, lane, out, shadows, cameras
+        self._done = False
+
+    def result(self):
+        if not self._done:
+            scene = self._scene
+            ok = scene._backend().render_wait(self._lane)
+            scene.__dict__.get("_pending", {}).pop(self._lane, None)
+            if not ok:          # a work list overflowed (now grown): render this frame's view again, synchronously
+                now = (scene.camera, scene.debug_camera)
+                scene.camera, scene.debug_camera = self._cameras
+                try:
+                    self._out = scene.render(shadows=self._shadows)
+                finally:
+                    scene.camera, scene.debug_camera = now
+            self._done = True
+        return self._out
+
+
 class Scene:
     """``Scene(camera, light, shadows, debug_camera, resolution=(H, W), system, subsystem,
     skymap)`` -- reference ``obj/core.py:558-640``.
@@ -401,6 +424,38 @@ class Scene:
         if report:
             self._print_face_report(backend.read_face_status())
         return out
+
+    def render_async(self, shadows=True):
+        """``render()`` without the wait: the frame's kernels and the copy of its uint8 rows to the host are
+        enqueued and the call returns a ``PendingFrame``; ``.result()`` hands out the array (the same bytes
+        ``render()`` would have returned).  Up to four frames may be pending on one scene; the copy of frame i
+        (longer than the frame's kernels at 1080p) then runs beside the kernels of frame i + 1 and beside the
+        host's preparation of frame i + 2.  The reference has no such call: it is an addition for sequences."""
+        backend = self._backend()
+        pending = self.__dict__.setdefault("_pending", {})
+        lane = next((k for k in range(backend.ASYNC_LANES) if k not in pending), None)
+        if lane is None:
+            raise RuntimeError("four frames of this scene are already pending: take one's result() first")
+        out = backend.render_async(self, lane, shadows=shadows, overlay=self.draw_debug_frustum)
+        frame = PendingFrame(self, lane, out, shadows, (self.camera, self.debug_camera))
+        pending[lane] = frame
+        return frame
+
+    def render_frames(self, views, shadows=True, depth=2):
+        """Frames of a sequence: for every ``(camera, debug_camera)`` pair of *views* the scene's cameras are set
+        and a frame is rendered; yields the uint8 arrays in order, *depth* frames in flight (``render_async``)."""
+        queue = []
+        try:
+            for camera, debug_camera in views:
+                self.camera, self.debug_camera = camera, debug_camera
+                queue.append(self.render_async(shadows=shadows))
+                if len(queue) >= max(1, int(depth)):
+                    yield queue.pop(0).result()
+            while queue:
+                yield queue.pop(0).result()
+        finally:
+            for frame in queue:
+                frame.result()
 
     def _print_face_report(self, status):
         from .triangular import Errors

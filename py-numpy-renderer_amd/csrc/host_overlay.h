@@ -75,16 +75,21 @@ struct OverlayLists {
     std::vector<int32_t> target[5], next[5];
     std::vector<double> z;
     std::vector<int32_t> touched;
+    std::vector<uint8_t> tile_mask;           // (want_tiles) the 16x16-pixel tiles that hold a target, row-major
 };
 
 // corners: the frustum's eight corners (8 x 4, already divided by w); faces: 6 x 4 corner indices
 inline void build_overlay_lists(const double *corners, const int32_t *faces, const double *planes, const double *mvp,
                                 const double *viewport, double near_, double far_, bool camera_inside,
-                                int height, int width, int dash, OverlayLists &out)
+                                int height, int width, int dash, OverlayLists &out, bool want_links = true,
+                                bool want_tiles = false)
 {
+    const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+    if (want_tiles) out.tile_mask.assign((size_t)tiles_x * tiles_y, 0);
     const double near_far = 2 * near_ * far_;
     const double f_plus_n = far_ + near_, f_minus_n = far_ - near_;
     std::vector<int64_t> rows, cols;            // raw (unwrapped) indices of the kept points
+    rows.reserve(16384); cols.reserve(16384);
     for (int f = 0; f < 6; ++f) {
         std::vector<Vec4> quad(4);
         for (int c = 0; c < 4; ++c)
@@ -145,7 +150,13 @@ inline void build_overlay_lists(const double *corners, const int32_t *faces, con
         out.target[2][i] = (int32_t)(wr * width + cm);
         out.target[3][i] = (int32_t)(rp * width + wc);
         out.target[4][i] = (int32_t)(wr * width + cp);
+        if (want_tiles) {
+            uint8_t *m = out.tile_mask.data();
+            m[(wr >> 4) * tiles_x + (wc >> 4)] = 1; m[(rm >> 4) * tiles_x + (wc >> 4)] = 1; m[(rp >> 4) * tiles_x + (wc >> 4)] = 1;
+            m[(wr >> 4) * tiles_x + (cm >> 4)] = 1; m[(wr >> 4) * tiles_x + (cp >> 4)] = 1;
+        }
     }
+    if (!want_links) return;                    // (the device needs neither the links nor the list of touched pixels)
     // next point (later in the same segment) with the same target: walk the segment backwards with a small
     // open-addressing table of (target -> latest point seen)
     std::vector<int32_t> keys, vals;

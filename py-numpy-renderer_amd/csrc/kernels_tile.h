@@ -189,6 +189,7 @@ struct TileArgs {
     uint32_t *bin_count;          // cursors = list lengths; zeroed again at the end of the tile
     const uint32_t *items[BIN_CLASSES];
     uint32_t cap[BIN_CLASSES];
+    const uint8_t *tap_mask;      // [n_tiles] or null: only the tiles marked here write the taps below (the overlay's tiles)
     double *zbuf;                 // optional taps (MR_FRAME_KEEP_BUFFERS): may be null
     int32_t *winner, *stencil;
     uint32_t *tile_stats;
@@ -224,7 +225,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
 
     // ---- 0. which tile, and what it lists
     int tile = 0, part = 0, n_parts = 1, entry = 0, n_tiles, ltr, gx, gy;
-    bool rh, counters, live, mat_lds;
+    bool rh, counters, live, mat_lds, taps;
     uint32_t n_small_raw, n_big_raw, n_quad_raw, n_small, n_big, n_quad, cost;
     unsigned long long t_start;
     {
@@ -288,8 +289,9 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         // the host has finalised already, or the skybox (no lists to walk, no barriers but the gamma table's).
         // Shadow quads over it only matter to the counters.
         const bool sky_tile = (fc.flags & MR_FRAME_SKYBOX) && sh.sky;
+        taps = (sh.frame || ta.zbuf) && (!ta.tap_mask || ta.tap_mask[tile]);
         if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (sky_tile || (fc.background_u8 >> 24)) &&
-            !sh.frame && !ta.zbuf) {
+            !taps) {
             if (part != 0) return;                        // (a tile that was heavy a frame ago: one part will do)
             uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
             if (sky_tile) {
@@ -733,7 +735,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
             ready_u8 = true;       // the host already finalised the colour with NumPy itself (obj/core.py:600,640)
         }
         const size_t at_px = (size_t)py * fc.width + px;
-        if (sh.frame) { sh.frame[at_px * 3 + 0] = rgb[0]; sh.frame[at_px * 3 + 1] = rgb[1]; sh.frame[at_px * 3 + 2] = rgb[2]; }
+        if (sh.frame && taps) { sh.frame[at_px * 3 + 0] = rgb[0]; sh.frame[at_px * 3 + 1] = rgb[1]; sh.frame[at_px * 3 + 2] = rgb[2]; }
         uint8_t *o = sh.out + ((size_t)out_row(fc, py, ltr) * fc.width + px) * 3;
         if (ready_u8) {
             o[0] = (uint8_t)fc.background_u8; o[1] = (uint8_t)(fc.background_u8 >> 8); o[2] = (uint8_t)(fc.background_u8 >> 16);
@@ -741,7 +743,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
 #pragma unroll
             for (int j = 0; j < 3; ++j) o[j] = gamma_u8(rgb[j], s_gamma);
         }
-        if (ta.zbuf) {                                    // taps for the parity tests / per-face status / overlay
+        if (ta.zbuf && taps) {                            // taps for the parity tests / per-face status / overlay
             ta.zbuf[at_px] = zbest;
             ta.winner[at_px] = best;
             ta.stencil[at_px] = sten;

@@ -103,6 +103,19 @@ struct FrameSlot {
     uint64_t last_serial = 0;                // the scene's frame serial when this slot last took a frame
     bool events_ok = false;
 
+    // this slot's device copy of the scene's overlay lists: ONE buffer filled with one asynchronous copy from a
+    // page-locked staging buffer on the slot's stream (behind the slot's earlier frames, in front of the next one),
+    // and the overlay kernel's scratch
+    struct OverlayCopy {
+        DevBuf lists, scratch;
+        void *staging = nullptr;
+        size_t staging_cap = 0;
+        size_t off[4] = {};                  // byte offsets of z, targets, segments, tile mask in `lists`
+        size_t state_entries = 0;            // entries of win / any in `scratch` (zero between frames)
+        uint64_t serial = 0;                 // the scene's ov_serial this copy holds
+        hipEvent_t copied = nullptr;         // the last copy out of the staging buffer
+    } ov;
+
     mr_frame_desc last_frame = {};
     int last_n_tiles = 0;
     bool last_ordered = false;               // the last frame's tile kernel followed the order buffer (else row-major)
@@ -115,6 +128,10 @@ struct FrameSlot {
                            &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_split,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
+        ov.lists.release(); ov.scratch.release();
+        if (ov.staging) (void)hipHostFree(ov.staging);
+        if (ov.copied) (void)hipEventDestroy(ov.copied);
+        ov.staging = nullptr; ov.staging_cap = 0; ov.serial = 0; ov.copied = nullptr;
         if (events_ok) {
             for (auto &set : ev_ring) for (auto &e : set) (void)hipEventDestroy(e);
             (void)hipHostFree(h_counters);
@@ -151,11 +168,24 @@ struct mr_scene {
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edges, d_edge_inc, d_face_n;
     DevBuf d_edges32;                        // the compact edge table, when the scene allows it
     bool edge_compact = false;
-    DevBuf d_ov_seg_first, d_ov_seg_count, d_ov_target, d_ov_next, d_ov_z, d_ov_touched, d_ov_keep, d_ov_blend;
-    int32_t ov_segments = 0, ov_points = 0, ov_touched = 0, ov_max_target = -1;     // debug-frustum overlay statement lists
+    // debug-frustum overlay: the level lists (host_overlay.h, OverlayLevels) in ONE device buffer, filled with one
+    // copy from a page-locked staging buffer on the library's stream, and the kernel's scratch
+    // debug-frustum overlay: the lines' points as built on the host (five targets and a depth per point, segment by
+    // segment); every frame slot keeps its own device copy (FrameSlot::ov), brought up to date when a frame of that
+    // slot draws the overlay
+    int32_t ov_height = 0, ov_width = 0;     // the frame the lists were built for
+    int32_t ov_points = 0, ov_segments = 0;
+    uint64_t ov_serial = 0;                  // bumped whenever the lists change
+    std::vector<int32_t> ov_target;          // (5, n_points) pixel row * width + col of every target
+    std::vector<double> ov_z;
+    std::vector<int32_t> ov_seg;             // first point, number of points per segment
+    std::vector<uint8_t> ov_tile_mask;       // the 16x16 tiles that hold a target
     DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
     DevBuf d_gamma;                          // GAMMA_LUT_SIZE float32 thresholds of the finalise step function
     int32_t sky_size = 0;
+
+    // ---- lanes of mr_render_async: a stream of the library's own each, and what is in flight on it
+    struct Lane { hipStream_t stream = nullptr; bool busy = false; } lanes[MR_ASYNC_LANES];
 
     // ---- frame slots, one per stream that has rendered this scene
     std::vector<std::unique_ptr<FrameSlot>> slots;
@@ -405,6 +435,60 @@ size_t out_bytes(const mr_frame_desc *fr)
     return (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
 }
 
+void fill_overlay_args(const mr_scene *sc, const FrameSlot *fs, mr::OverlayArgs &oa)
+{
+    const char *base = static_cast<const char *>(fs->ov.lists.p);
+    oa.z = reinterpret_cast<const double *>(base + fs->ov.off[0]);
+    oa.idx = reinterpret_cast<const int32_t *>(base + fs->ov.off[1]);
+    oa.seg = reinterpret_cast<const int32_t *>(base + fs->ov.off[2]);
+    oa.n_points = sc->ov_points; oa.n_segments = sc->ov_segments;
+    char *scratch = static_cast<char *>(fs->ov.scratch.p);
+    oa.win = reinterpret_cast<uint32_t *>(scratch);
+    oa.any = oa.win + fs->ov.state_entries;
+    oa.keep = reinterpret_cast<uint8_t *>(oa.any + fs->ov.state_entries);
+    oa.pixel_of = nullptr;
+}
+
+// Brings the slot's device copy of the overlay lists up to date: packed into the slot's page-locked staging buffer
+// and copied with ONE asynchronous copy on the slot's stream (behind the slot's earlier frames, which read the old
+// lists, and in front of the frame that needs the new ones).  The staging buffer is rewritten only after the copy
+// that last read it has completed (an event; mr_render and mr_render_wait have drained the stream long before).
+int sync_slot_overlay(mr_scene *sc, FrameSlot *fs)
+{
+    if (fs->ov.serial == sc->ov_serial || sc->ov_points == 0) return MR_OK;
+    const void *src[4] = { sc->ov_z.data(), sc->ov_target.data(), sc->ov_seg.data(), sc->ov_tile_mask.data() };
+    const size_t bytes[4] = { sc->ov_z.size() * 8, sc->ov_target.size() * 4, sc->ov_seg.size() * 4, sc->ov_tile_mask.size() };
+    size_t total = 0;
+    for (int i = 0; i < 4; ++i) { fs->ov.off[i] = total; total += (bytes[i] + 15) & ~(size_t)15; }
+    // scratch: win and any (one word per pixel of the frame each, zero between segments and frames)
+    const size_t entries = (size_t)sc->ov_height * sc->ov_width;
+    const size_t scratch = entries * 8 + (size_t)sc->ov_points + 16;
+    if (total > fs->ov.staging_cap || total > fs->ov.lists.cap || scratch > fs->ov.scratch.cap)
+        HIP_TRY(hipStreamSynchronize(fs->stream));          // (growing frees the old buffers: nothing may still use them)
+    if (total > fs->ov.staging_cap) {
+        if (fs->ov.staging) (void)hipHostFree(fs->ov.staging);
+        fs->ov.staging = nullptr; fs->ov.staging_cap = 0;
+        HIP_TRY(hipHostMalloc(&fs->ov.staging, total + total / 2, hipHostMallocDefault));
+        fs->ov.staging_cap = total + total / 2;
+    }
+    if (!fs->ov.copied) HIP_TRY(hipEventCreateWithFlags(&fs->ov.copied, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(fs->ov.copied));
+    for (int i = 0; i < 4; ++i) std::memcpy(static_cast<char *>(fs->ov.staging) + fs->ov.off[i], src[i], bytes[i]);
+    HIP_TRY(fs->ov.lists.ensure(total));
+    {
+        const void *had = fs->ov.scratch.p;
+        const size_t had_entries = fs->ov.state_entries;
+        HIP_TRY(fs->ov.scratch.ensure(scratch));
+        if (fs->ov.scratch.p != had || had_entries != entries)      // the kernel leaves win / any zeroed; a new layout starts so
+            HIP_TRY(hipMemsetAsync(fs->ov.scratch.p, 0, fs->ov.scratch.cap, fs->stream));
+        fs->ov.state_entries = entries;
+    }
+    HIP_TRY(hipMemcpyAsync(fs->ov.lists.p, fs->ov.staging, total, hipMemcpyHostToDevice, fs->stream));
+    HIP_TRY(hipEventRecord(fs->ov.copied, fs->stream));
+    fs->ov.serial = sc->ov_serial;
+    return MR_OK;
+}
+
 // Enqueues one frame on the slot's stream.  d_out receives the uint8 rows.
 int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t *d_out)
 {
@@ -415,11 +499,15 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     FrameConst fc = make_const(sc, fr);
     if (fc.flags & MR_FRAME_FACE_STATUS) fc.flags |= MR_FRAME_KEEP_BUFFERS;
     const bool overlay = (fc.flags & MR_FRAME_OVERLAY) && sc->ov_points > 0;
+    // did the caller ask for the z / stencil / winner / float-frame taps?  (The overlay needs z and colour too, but
+    // only at the pixels its lines touch: then only the tiles that hold such a pixel write them, ov_off[7].)
+    const bool taps_asked = (fc.flags & (MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT)) != 0;
     if (fc.flags & MR_FRAME_OVERLAY) {
         if (fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1)
             return fail(MR_E_INVALID, "the debug-frustum overlay needs the whole frame on one device (no row band, no stripes)");
-        if ((long long)sc->ov_max_target >= (long long)fc.width * fc.height)
-            return fail(MR_E_INVALID, "overlay statement lists were built for a larger frame");
+        if (sc->ov_points > 0 && (sc->ov_width != fc.width || sc->ov_height != fc.height))
+            return fail(MR_E_INVALID, "overlay lists were built for a frame of another size");
+        if (overlay && (rc = sync_slot_overlay(sc, fs))) return rc;
         fc.flags |= MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT;
     }
     const size_t npx = (size_t)fc.width * fc.height;
@@ -549,6 +637,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ta.clips = fs->d_clips.as<TriClip>(); ta.quads = fs->d_quads.as<QuadRec>();
     ta.bin_count = fs->d_bin_count.as<uint32_t>();
     for (int c = 0; c < BIN_CLASSES; ++c) { ta.items[c] = fs->d_items[c].as<uint32_t>(); ta.cap[c] = fs->bin_cap[c]; }
+    ta.tap_mask = (overlay && !taps_asked) ? reinterpret_cast<const uint8_t *>(static_cast<const char *>(fs->ov.lists.p) + fs->ov.off[3])
+                                           : nullptr;
     ta.zbuf = keep ? fs->d_z.as<double>() : nullptr;
     ta.winner = keep ? fs->d_winner.as<int32_t>() : nullptr;
     ta.stencil = keep ? fs->d_stencil.as<int32_t>() : nullptr;
@@ -608,14 +698,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                            fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>());
     if (overlay) {                          // after the lit pass' per-face verdicts, as in obj/core.py:624-638
         OverlayArgs oa;
-        oa.seg_first = sc->d_ov_seg_first.as<int32_t>(); oa.seg_count = sc->d_ov_seg_count.as<int32_t>();
-        oa.target = sc->d_ov_target.as<int32_t>(); oa.next = sc->d_ov_next.as<int32_t>();
-        oa.z = sc->d_ov_z.as<double>(); oa.touched = sc->d_ov_touched.as<int32_t>();
-        oa.n_segments = sc->ov_segments; oa.n_points = sc->ov_points; oa.n_touched = sc->ov_touched;
-        oa.keep = sc->d_ov_keep.as<uint8_t>(); oa.blend = sc->d_ov_blend.as<float>();
-        oa.zbuf = fs->d_z.as<double>(); oa.frame = fs->d_frame.as<float>(); oa.out = d_out;
+        fill_overlay_args(sc, fs, oa);
+        // on the frame's own z-buffer and float frame (so the debug taps show them after the overlay, like upstream's)
+        oa.st_z = fs->d_z.as<double>(); oa.st_f = fs->d_frame.as<float>(); oa.out = d_out;
+        oa.out_width = fc.width; oa.out_height = fc.height;
         oa.gamma_lut = sc->d_gamma.as<float>();
-        hipLaunchKernelGGL(k_overlay, dim3(1), dim3(OVERLAY_BLOCK), 0, stream, fc, oa);
+        hipLaunchKernelGGL(k_overlay, dim3(1), dim3(OVERLAY_BLOCK), 0, stream, oa, (double)fc.system);
     }
     HIP_TRY(hipGetLastError());
     fs->last_frame = *fr;
@@ -798,10 +886,10 @@ void mr_scene_destroy(mr_scene *sc)
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
                        &sc->d_textures, &sc->d_edges, &sc->d_edges32, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma,
-                       &sc->d_ov_seg_first, &sc->d_ov_seg_count, &sc->d_ov_target, &sc->d_ov_next, &sc->d_ov_z,
-                       &sc->d_ov_touched, &sc->d_ov_keep, &sc->d_ov_blend };
+                       };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();
+    for (auto &ln : sc->lanes) if (ln.stream) (void)hipStreamDestroy(ln.stream);
     delete sc;
 }
 
@@ -843,49 +931,70 @@ int mr_scene_set_overlay(mr_scene *sc, const mr_overlay_desc *ov)
     if (!sc) return fail(MR_E_INVALID, "scene is NULL");
     int rc = ensure_init();
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());          // no frame may still be replaying the old lists
-    sc->ov_segments = sc->ov_points = sc->ov_touched = 0;
-    sc->ov_max_target = -1;
+    sc->ov_points = sc->ov_segments = 0;                 // (frames already enqueued keep the lists of their slot's copy)
+    sc->ov_serial += 1;
     if (!ov || ov->n_points <= 0 || ov->n_segments <= 0) return MR_OK;
-    if (!ov->seg_first || !ov->seg_count || !ov->target || !ov->next || !ov->z || (ov->n_touched > 0 && !ov->touched))
+    if (!ov->seg_first || !ov->seg_count || !ov->target || !ov->z)
         return fail(MR_E_INVALID, "overlay description has NULL arrays");
+    if (ov->width <= 0 || ov->height <= 0 || ov->width > 32767 || ov->height > 32767)
+        return fail(MR_E_INVALID, "overlay description: bad frame size");
     const int np = ov->n_points;
-    // validate before the kernel trusts them: segments inside the point range, links inside their own
-    // segment and pointing forward (so every chain ends), targets non-negative
-    std::vector<int32_t> seg_of((size_t)np, -1);
+    // validate before the kernel trusts them: segments inside the point range, one after the other; targets pixels
+    // of the frame the description names
+    long long expect = 0;
     for (int s = 0; s < ov->n_segments; ++s) {
         const long long first = ov->seg_first[s], count = ov->seg_count[s];
-        if (first < 0 || count < 0 || first + count > np) return fail(MR_E_INVALID, "overlay segment outside the point array");
-        for (long long p = first; p < first + count; ++p) seg_of[(size_t)p] = s;
+        if (first != expect || count <= 0 || first + count > np)
+            return fail(MR_E_INVALID, "overlay segments must follow each other and cover the point array");
+        if (count > mr::OVERLAY_MAX_SEGMENT) return fail(MR_E_INVALID, "overlay segment longer than a frame is wide or high");
+        expect = first + count;
     }
+    if (expect != np) return fail(MR_E_INVALID, "overlay segments must follow each other and cover the point array");
     int32_t max_target = -1;
-    for (int k = 0; k < mr::OVERLAY_TARGETS; ++k)
-        for (int p = 0; p < np; ++p) {
-            const int32_t t = ov->target[(size_t)k * np + p], nx = ov->next[(size_t)k * np + p];
-            if (t < 0) return fail(MR_E_INVALID, "negative overlay target");
-            max_target = std::max(max_target, t);
-            if (nx != -1 && (nx <= p || nx >= np || seg_of[(size_t)nx] != seg_of[(size_t)p]))
-                return fail(MR_E_INVALID, "overlay link must point forward inside its own segment");
-        }
-    for (int i = 0; i < ov->n_touched; ++i) {
-        if (ov->touched[i] < 0) return fail(MR_E_INVALID, "negative overlay target");
-        max_target = std::max(max_target, ov->touched[i]);
+    for (size_t i = 0; i < (size_t)mr::OVERLAY_TARGETS * np; ++i) {
+        if (ov->target[i] < 0) return fail(MR_E_INVALID, "negative overlay target");
+        max_target = std::max(max_target, ov->target[i]);
     }
-    auto up = [&](DevBuf &buf, const void *src, size_t bytes) -> int {
-        HIP_TRY(buf.ensure(std::max<size_t>(bytes, 16)));
-        if (bytes) HIP_TRY(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
-        return MR_OK;
-    };
-    if ((rc = up(sc->d_ov_seg_first, ov->seg_first, (size_t)ov->n_segments * 4))) return rc;
-    if ((rc = up(sc->d_ov_seg_count, ov->seg_count, (size_t)ov->n_segments * 4))) return rc;
-    if ((rc = up(sc->d_ov_target, ov->target, (size_t)mr::OVERLAY_TARGETS * np * 4))) return rc;
-    if ((rc = up(sc->d_ov_next, ov->next, (size_t)mr::OVERLAY_TARGETS * np * 4))) return rc;
-    if ((rc = up(sc->d_ov_z, ov->z, (size_t)np * 8))) return rc;
-    if ((rc = up(sc->d_ov_touched, ov->touched, (size_t)std::max(ov->n_touched, 0) * 4))) return rc;
-    HIP_TRY(sc->d_ov_keep.ensure((size_t)np));
-    HIP_TRY(sc->d_ov_blend.ensure((size_t)np * 3 * sizeof(float)));
-    sc->ov_segments = ov->n_segments; sc->ov_points = np; sc->ov_touched = std::max(ov->n_touched, 0);
-    sc->ov_max_target = max_target;
+    if ((long long)max_target >= (long long)ov->width * ov->height)
+        return fail(MR_E_INVALID, "overlay description: targets outside the height x width it names");
+    sc->ov_target.assign(ov->target, ov->target + (size_t)mr::OVERLAY_TARGETS * np);
+    sc->ov_z.assign(ov->z, ov->z + np);
+    sc->ov_seg.resize((size_t)2 * ov->n_segments);
+    for (int i = 0; i < ov->n_segments; ++i) { sc->ov_seg[2 * i] = ov->seg_first[i]; sc->ov_seg[2 * i + 1] = ov->seg_count[i]; }
+    const int tiles_x = (ov->width + mr::TILE_W - 1) / mr::TILE_W, tiles_y = (ov->height + mr::TILE_H - 1) / mr::TILE_H;
+    sc->ov_tile_mask.assign((size_t)tiles_x * tiles_y, 0);
+    for (int32_t t : sc->ov_target) sc->ov_tile_mask[(size_t)(t / ov->width / mr::TILE_H) * tiles_x + (size_t)(t % ov->width / mr::TILE_W)] = 1;
+    sc->ov_height = ov->height; sc->ov_width = ov->width;
+    sc->ov_points = np; sc->ov_segments = ov->n_segments;
+    return MR_OK;
+}
+
+int mr_scene_set_overlay_cameras(mr_scene *sc, const double *corners, const double *planes, const double *mvp,
+                                 const double *viewport, double near_, double far_, int32_t camera_inside,
+                                 int32_t height, int32_t width)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    if (!corners || !planes || !mvp || !viewport || height <= 0 || width <= 0 || height > 32767 || width > 32767)
+        return fail(MR_E_INVALID, "mr_scene_set_overlay_cameras: bad argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    static const int32_t faces[24] = { 2, 4, 5, 3,  0, 1, 7, 6,  0, 2, 3, 1,  5, 4, 6, 7,  3, 5, 7, 1,  4, 2, 0, 6 };
+    static thread_local mr_host::OverlayLists lists;            // (its vectors keep their capacity from call to call)
+    lists.seg_first.clear(); lists.seg_count.clear(); lists.z.clear();
+    mr_host::build_overlay_lists(corners, faces, planes, mvp, viewport, near_, far_, camera_inside != 0, height, width, 13,
+                                 lists, false, true);
+    sc->ov_points = sc->ov_segments = 0;
+    sc->ov_serial += 1;
+    if (lists.z.empty()) return MR_OK;
+    const size_t np = lists.z.size();
+    sc->ov_target.resize((size_t)mr::OVERLAY_TARGETS * np);
+    for (int k = 0; k < mr::OVERLAY_TARGETS; ++k) std::copy(lists.target[k].begin(), lists.target[k].end(), sc->ov_target.begin() + (size_t)k * np);
+    sc->ov_z.assign(lists.z.begin(), lists.z.end());
+    sc->ov_seg.resize(2 * lists.seg_first.size());
+    for (size_t i = 0; i < lists.seg_first.size(); ++i) { sc->ov_seg[2 * i] = lists.seg_first[i]; sc->ov_seg[2 * i + 1] = lists.seg_count[i]; }
+    sc->ov_tile_mask.swap(lists.tile_mask);
+    sc->ov_height = height; sc->ov_width = width;
+    sc->ov_points = (int32_t)np; sc->ov_segments = (int32_t)lists.seg_first.size();
     return MR_OK;
 }
 
@@ -986,6 +1095,44 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
         if (rc != MR_E_OVERFLOW) return rc;       // work lists were grown: render the frame again
     }
     return fail(MR_E_OVERFLOW, "work lists kept overflowing");
+}
+
+int mr_render_async(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, int32_t lane)
+{
+    if (!sc || !out_rgb) return fail(MR_E_INVALID, "NULL argument");
+    if (lane < 0 || lane >= MR_ASYNC_LANES) return fail(MR_E_INVALID, "lane out of range");
+    int rc = validate_frame(fr);
+    if (rc) return rc;
+    if ((rc = ensure_init())) return rc;
+    mr_scene::Lane &ln = sc->lanes[lane];
+    if (ln.busy) return fail(MR_E_INVALID, "this lane still has a frame in flight: mr_render_wait first");
+    if (!ln.stream) HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    FrameSlot *fs = slot_for(sc, ln.stream);
+    if (!fs) return fail(MR_E_DEVICE, "out of frame slots");
+    const size_t band_bytes = out_bytes(fr);
+    HIP_TRY(fs->d_out.ensure(band_bytes));
+    if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
+    if ((rc = fetch_counters(sc, fs, (fr->flags & MR_FRAME_COUNTERS) != 0))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, ln.stream));
+    if (!(fr->flags & MR_FRAME_NO_TIMING)) HIP_TRY(hipEventRecord(fs->ev[5], ln.stream));
+    ln.busy = true;
+    return MR_OK;
+}
+
+int mr_render_wait(mr_scene *sc, int32_t lane, mr_stats *stats)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    if (lane < 0 || lane >= MR_ASYNC_LANES) return fail(MR_E_INVALID, "lane out of range");
+    mr_scene::Lane &ln = sc->lanes[lane];
+    if (!ln.busy) return fail(MR_E_INVALID, "no frame in flight on this lane");
+    HIP_TRY(hipStreamSynchronize(ln.stream));
+    ln.busy = false;
+    FrameSlot *fs = slot_for(sc, ln.stream);
+    if (!fs) return fail(MR_E_DEVICE, "lane without a frame slot");
+    const int rc = collect(sc, fs, true);
+    if (stats) *stats = sc->stats;
+    if (rc == MR_E_OVERFLOW) return fail(MR_E_OVERFLOW, "the frame overflowed a work list (now grown): render it again");
+    return rc;
 }
 
 void *mr_host_alloc(uint64_t bytes)

@@ -37,6 +37,15 @@ def bresenham_line(start_point, end_point):
     return start_point + np.arange(int(steps))[:, None] * (delta / steps)
 
 
+def frustum_corners(camera, positioned_object):
+    """World-space corners of *positioned_object*'s frustum (8 x 4, divided by w) and whether *camera* sits inside
+    it (``obj/frustums.py:52-60``): the part of the recipe that stays with NumPy (a matrix inverse)."""
+    corners = CUBE @ np.linalg.inv(positioned_object.MVP)
+    corners /= corners[W_COL]
+    probe = np.append(camera.position, 1) @ positioned_object.MVP
+    return corners, all(-probe[3] < probe[k] < probe[3] for k in range(3))
+
+
 def overlay_segments(camera, positioned_object):
     """The line segments of *positioned_object*'s frustum as seen by *camera*, in drawing order: a
     list of ``(row, col, z)`` arrays (int32, int32, float64; row = screen y, not flipped), one per
@@ -190,6 +199,40 @@ class OverlayOps:
                 zf[cn] = zk
                 ff[rn] = ff[rn] * 0.5 + half_red
                 ff[cn] = ff[cn] * 0.5 + half_red
+
+
+def replay_bids(ops, frame, z_buffer, sign):
+    """NumPy restatement of what the DEVICE does with the lists (``csrc/kernels_overlay.h``, three phases per
+    segment): the kept (target set k, point p) of a segment bid for their target pixels with ``code = k << 26 | p``
+    (``atomicMax``) and leave their k in a bit mask (``atomicOr``); the winning bidder of every pixel writes its own
+    z (it is the last kept writer in statement order), turns the pixel red if a kept point has it as its centre and
+    half-blends it once for every k = 1..4 that has a kept point on it.  The CPU tests hold this equal to
+    ``OverlayOps.replay``, the statement-by-statement restatement of upstream."""
+    zf, ff = z_buffer.reshape(-1), frame.reshape(-1, 3)
+    win, anyk = np.zeros(zf.size, np.uint32), np.zeros(zf.size, np.uint32)
+    for first, count in zip(ops.seg_first, ops.seg_count):
+        sl = slice(first, first + count)
+        z = ops.z[sl]
+        keep = np.nonzero((zf[ops.target[0, sl]] - z) * sign >= 0)[0]
+        if len(keep) == 0:
+            continue
+        ks = np.repeat(np.arange(5, dtype=np.uint32), len(keep))
+        qs = np.tile(keep.astype(np.uint32), 5)
+        X = ops.target[:, sl][:, keep].reshape(-1)
+        code = (ks << np.uint32(26) | qs) + np.uint32(1)
+        np.maximum.at(win, X, code)
+        np.bitwise_or.at(anyk, X, np.uint32(1) << ks)
+        won = win[X] == code
+        Xw, qw = X[won], qs[won]
+        zf[Xw] = z[qw]
+        f = ff[Xw].copy()
+        f[(anyk[Xw] & 1) != 0] = RED
+        for k in range(1, 5):
+            hit = (anyk[Xw] & (1 << k)) != 0
+            f[hit] = (f[hit] * np.float32(0.5) + RED / 2).astype(np.float32)
+        ff[Xw] = f
+        win[Xw] = 0
+        anyk[Xw] = 0
 
 
 def draw_view_frustum(frame, camera, positioned_object, z_buffer, sign):

@@ -517,3 +517,44 @@ def test_random_views_against_oracle(api, oracle_mod):
         out, _ = _against_oracle(api, oracle_mod, sc, label=f"random view {i}")
         assert np.array_equal(sc.render(), out), f"random view {i}: frame-only mode differs"
         sc.close()
+
+
+def test_pipelined_frames_equal_synchronous_ones(api):
+    """Scene.render_frames / render_async (mr_render_async + mr_render_wait: two to four frames in flight on the
+    library's lanes, the host copy of one frame running beside the kernels of the next): sixteen frames of a moving
+    camera, overlay on as by default, must be the sixteen frames render() returns one at a time -- also when the
+    work lists start far too small and every lane has to grow them."""
+    scene = scenes.build(api, "diablo_floor_small")
+    scene.draw_debug_frustum = True
+    kw = dict(fovy=60, near=0.1, far=20, backface_culling=True)
+
+    def views():
+        for k in range(16):
+            pos = (0.5 + 0.02 * k, 1.0, 2.0 - 0.015 * k)
+            yield api.Camera(pos, (0, 0, 0), **kw), api.Camera(pos, (0, 0, 0), **kw)
+
+    want = []
+    for cam, dbg in views():
+        scene.camera, scene.debug_camera = cam, dbg
+        want.append(scene.render().copy())
+    assert any(not np.array_equal(want[0], w) for w in want[1:])
+    for depth in (2, 4):
+        got = [f.copy() for f in scene.render_frames(views(), depth=depth)]
+        assert len(got) == 16
+        for k in range(16):
+            assert np.array_equal(got[k], want[k]), f"depth {depth}: frame {k} differs"
+    pending = [scene.render_async() for _ in range(4)]
+    with pytest.raises(RuntimeError):
+        scene.render_async()
+    last = [p.result() for p in pending]
+    assert all(np.array_equal(f, want[-1]) for f in last)
+    scene.close()
+
+    scene = scenes.build(api, "diablo_floor_small")
+    scene._backend().set_list_capacities(small_pairs=4, big_pairs=2, quads=3, work=16)
+    got = [f.copy() for f in scene.render_frames(views(), depth=3)]
+    scene.draw_debug_frustum = False
+    for k, (cam, dbg) in enumerate(views()):
+        scene.camera, scene.debug_camera = cam, dbg
+        assert np.array_equal(got[k], scene.render()), f"small lists: frame {k} differs"
+    scene.close()

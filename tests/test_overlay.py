@@ -67,6 +67,12 @@ def test_scene_render_with_overlay_matches_reference(api, name):
     assert np.abs(backend.read_frame_f32().astype(np.float64) - g["frame_overlay"].astype(np.float64)).max() <= 2e-6
     plain = backend.render(scene, counters=False)
     assert (plain != out).any(), "the overlay drew nothing"
+    # the explicit-lists entry point (mr_scene_set_overlay, fed by the NumPy walk) draws the same overlay
+    from py_numpy_renderer_amd.frustums import OverlayOps
+    backend.set_overlay_lists(OverlayOps(scene.camera, scene.debug_camera, scene.resolution, native=False))
+    assert np.array_equal(backend.render(scene, counters=False, keep_buffers=False, overlay=True), out)
+    backend.set_overlay_lists(OverlayOps(scene.camera, scene.debug_camera, scene.resolution, native=False), pin=False)
+    assert np.array_equal(scene.render(), out)
     scene.close()
 
 
@@ -120,3 +126,42 @@ def test_native_list_builder_equals_the_numpy_walk():
         n_points += a.n_points
         dashed += int(len(a.seg_count) > 0 and a.seg_count.min() < 30)
     assert n_points > 20000 and dashed > 10          # the trials did draw something, short (dashed / clipped) segments included
+
+
+def test_device_scheme_replays_like_the_statement_lists():
+    """What the device does with the lists (per segment: keep flags, bids, the winning bidder applies the segment to
+    its pixel -- csrc/kernels_overlay.h, restated in NumPy by frustums.replay_bids) against the statement-by-statement
+    replay that restates upstream (OverlayOps.replay), on random z-buffers and frames: z bit for bit, the float
+    frame bit for bit -- 60 random camera pairs incl. the border-and-diagonal case (debug camera == camera)."""
+    import py_numpy_renderer_amd as pkg
+    from py_numpy_renderer_amd.frustums import OverlayOps, replay_bids
+    rng = np.random.default_rng(7)
+    points = 0
+    for trial in range(60):
+        lh = trial % 3 == 0
+        system, subsystem = (pkg.SYSTEM.LH, pkg.SUBSYSTEM.OPENGL) if lh else (pkg.SYSTEM.RH, pkg.SUBSYSTEM.DIRECTX)
+        res = (int(rng.integers(40, 160)), int(rng.integers(40, 220)))
+        kw = dict(fovy=float(rng.choice([30, 60, 90])), near=0.1, far=float(rng.choice([5.0, 20.0])), backface_culling=True)
+        eye = rng.standard_normal(3) * 2 + np.array([0.5, 1.0, 2.0])
+        cam = pkg.Camera(tuple(eye), (0, 0, 0), **kw)
+        if trial % 4 == 0:
+            dbg = pkg.Camera(tuple(eye), (0, 0, 0), **kw)
+        else:
+            kd = dict(kw, fovy=float(rng.choice([20, 45, 80])), near=float(rng.choice([0.2, 1.0])), far=float(rng.choice([3.0, 8.0])) + 1.0)
+            dbg = pkg.Camera(tuple(rng.standard_normal(3) * 1.5 + np.array([0.0, 1.0, 0.5])), tuple(rng.standard_normal(3) * 0.3), **kd)
+        pkg.Scene(cam, pkg.Light((2, 3, 4)), debug_camera=dbg, resolution=res, system=system, subsystem=subsystem)
+        ops = OverlayOps(cam, dbg, res, native=False)
+        if ops.n_points == 0:
+            continue
+        sign = -1 if lh else 1
+        # a z-buffer the lines partly pass and partly fail against: around the lines' own depths
+        z0 = rng.choice(ops.z, size=res) * rng.uniform(0.7, 1.4, size=res)
+        f0 = rng.uniform(0.05, 1.0, size=res + (3,)).astype(np.float32)
+        za, fa, zb, fb = z0.copy(), f0.copy(), z0.copy(), f0.copy()
+        ops.replay(fa, za, sign)
+        replay_bids(ops, fb, zb, sign)
+        assert np.array_equal(za.view(np.uint64), zb.view(np.uint64)), trial
+        assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), trial
+        assert not np.array_equal(za, z0)
+        points += ops.n_points
+    assert points > 5000
