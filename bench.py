@@ -14,7 +14,7 @@ A frame is the whole hot path: per-frame constants in, vertex transform, face se
 + shadow-quad set-up, binning, tile visibility (coverage, z, stencil), deferred shading and
 finalise to uint8, with the scene already resident in HBM and the frame left in HBM
 (``mr_render_device``).  A STEP is a batch of frames -- at least ``--frames-per-step`` (default 256), and as
-many as it takes for the K timed steps to last 0.6 s at the rate of a short calibration run (``frames_per_step``
+many as it takes for the K timed steps to last 3 s at the rate of a short calibration run (``frames_per_step``
 in the line says how many) -- so the timed region does not depend on --steps; successive frames use DIFFERENT per-frame
 constants (the camera swings through 8 slightly different views), and ``--frames-in-flight``
 (default 3) of them are in flight on separate HIP streams.  With N > 1 every rank renders its share
@@ -46,6 +46,40 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 N_VIEWS = 8
+TIMED_SECONDS = 3.0          # the K timed steps together last at least this long
+N_SIMDS = 1024               # 256 CUs x 4 SIMDs
+
+
+def valu_roofline(config, launch_ms, solo_ms):
+    """The tile kernel's VECTOR-ISSUE bound: its vector instructions by class (rocprofv3 SQ_INSTS_VALU_* of this
+    config, profiles/r03_<config>_valu_mix.json) priced with the SIMD time a wave-instruction of that class takes
+    on MI355X (tools/micro/valu_f64_rate.hip, measured on the same pool: profiles/r03_valu_rate.txt, the column for
+    six wavefronts per SIMD), spread over the chip's 1 024 SIMDs."""
+    mix_path = os.path.join(ROOT, "profiles", f"r03_{config}_valu_mix.json")
+    rate_path = os.path.join(ROOT, "profiles", "r03_valu_rate.txt")
+    if not (os.path.exists(mix_path) and os.path.exists(rate_path)):
+        return None
+    with open(mix_path) as fh:
+        mix = json.load(fh)["per_launch"]["k_tile"]
+    ns = {}
+    with open(rate_path) as fh:
+        for line in fh:
+            if "6/SIMD" in line and "chain" not in line:
+                name = line.split("  ")[0].strip()
+                ns[name] = float(line.split("6/SIMD")[1].split("t")[1].split("ns")[0])
+    cost = {"SQ_INSTS_VALU_FMA_F64": ns["v_fma_f64"], "SQ_INSTS_VALU_MUL_F64": ns["v_mul_f64"], "SQ_INSTS_VALU_ADD_F64": ns["v_add_f64"],
+            "SQ_INSTS_VALU_TRANS_F64": ns["v_rcp_f64"], "SQ_INSTS_VALU_CVT": ns["v_cvt_f64_f32"]}
+    classified = sum(mix.get(k, 0) for k in cost)
+    other = mix["SQ_INSTS_VALU"] - classified          # 32-bit arithmetic, compares, selects, moves: the v_add_u32 / v_fma_f32 rate
+    simd_ns = sum(mix.get(k, 0) * c for k, c in cost.items()) + other * max(ns["v_add_u32"], ns["v_fma_f32"])
+    issue_us = simd_ns / N_SIMDS / 1e3
+    return {"bound": "valu", "kernel": "k_tile", "instructions": int(mix["SQ_INSTS_VALU"]),
+            "float64_instructions": int(sum(mix.get(k, 0) for k in list(cost)[:4])),
+            "ns_per_wave_instruction": {k.replace("SQ_INSTS_VALU_", "").lower(): c for k, c in cost.items()} | {"other": max(ns["v_add_u32"], ns["v_fma_f32"])},
+            "issue_us_per_launch": round(issue_us, 2), "unit": "us of SIMD time per launch, spread over 1 024 SIMDs",
+            "frac": round(issue_us / (launch_ms * 1e3), 4) if launch_ms > 0 else None,
+            "solo_frac": round(issue_us / (solo_ms * 1e3), 4) if solo_ms > 0 else None,
+            "source": "profiles/r03_%s_valu_mix.json x profiles/r03_valu_rate.txt" % config}
 
 CONFIGS = {
     "c2": ("c2_diablo_1080p", "diablo3_pose (5 022 tris), 1920x1080, Phong + normal map, z-buffer only (BASELINE.json configs[1] / BASELINE.md c2)"),
@@ -227,9 +261,10 @@ def main():
     if not br.verify():                  # a work list overflowed during warm-up: it has been grown, warm up again
         run(br, args.warmup * fps)
         assert br.verify(), "work lists kept overflowing"
-    # A step is a batch of frames, sized so that the K timed steps last at least ~0.6 s whatever the config and
-    # however fast a frame has become (the default 256 did that for c4 until a frame dropped under 0.1 ms): the
-    # rate of a short calibration run (untimed as far as the result goes) decides, the same on every rank.
+    # A step is a batch of frames, sized so that the K timed steps last at least ~3 s whatever the config and
+    # however fast a frame has become (long enough for an outside observer sampling the device once a second to
+    # land inside the timed region): the rate of a short calibration run (untimed as far as the result goes)
+    # decides, the same on every rank.
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(br, 256)
@@ -237,7 +272,7 @@ def main():
     est = torch.tensor([(time.perf_counter() - t0) / 256], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(est, op=dist.ReduceOp.MAX)
-    need = int(0.6 / (max(args.steps, 1) * max(float(est.item()), 1e-6))) + 1
+    need = int(TIMED_SECONDS / (max(args.steps, 1) * max(float(est.item()), 1e-6))) + 1
     fps = max(fps, -(-need // 8) * 8)
     torch.cuda.synchronize()
     if world > 1:
@@ -293,7 +328,8 @@ def main():
     counted.set_descriptors(descriptors(True, True))
     per_frame_counted = timed(counted, n_side)
 
-    host_ms = host_overlay_ms = host_same_ms = host_overlay_same_ms = None
+    host_ms = host_overlay_ms = host_same_ms = host_overlay_same_ms = pipe_ms = pipe_overlay_ms = None
+    protocol_ms = protocol_copy_ms = None
     if rank == 0 and world == 1:
         # the drop-in call as a user makes it: Scene.render() returning the uint8 ndarray (packing of the
         # per-frame constants, upload, the three kernels, device->host copy into page-locked memory), first
@@ -320,14 +356,41 @@ def main():
             scene.camera, scene.debug_camera = base_cameras
             return sorted(samples)[len(samples) // 2] * 1e3
 
+        def pipelined(n=48, depth=3):
+            # the same frames as a sequence: Scene.render_frames keeps `depth` frames in flight (mr_render_async), so the
+            # host copy of one frame runs beside the kernels of the next and the host's preparation of the one after
+            cams = lambda off: (swing_cameras(api, scene_base, 1, offset=off + k)[0] for k in range(n))
+            for _ in scene.render_frames((swing_cameras(api, scene_base, 1, offset=500 + k)[0] for k in range(6)), shadows=shadows, depth=depth):
+                pass
+            t0 = time.perf_counter()
+            for _ in scene.render_frames(cams(0), shadows=shadows, depth=depth):
+                pass
+            dt = (time.perf_counter() - t0) / n
+            scene.camera, scene.debug_camera = base_cameras
+            return dt * 1e3
+
         scene_base = scene
         scene.draw_debug_frustum = False
         host_ms = host_median(True)
         host_same_ms = host_median(False)
+        pipe_ms = pipelined()
         scene.draw_debug_frustum = True
         host_overlay_ms = host_median(True)
         host_overlay_same_ms = host_median(False)
+        pipe_overlay_ms = pipelined()
         scene.draw_debug_frustum = False
+        # SURVEY 8(d)'s protocol: one frame at a time, HIP events around the whole device section of mr_render
+        # (per-frame constants, the three kernels, the copy of the uint8 frame into page-locked host memory), median
+        spans = []
+        for k in range(40):
+            scene.camera, scene.debug_camera = swing_cameras(api, scene_base, 1, offset=k)[0]
+            backend.render(scene, shadows=shadows, counters=False, keep_buffers=False, timing=True)
+            st = backend.stats()
+            if k >= 8:
+                spans.append((st["gpu_ms_total"], st["gpu_ms_copy"]))
+        scene.camera, scene.debug_camera = base_cameras
+        spans.sort()
+        protocol_ms, protocol_copy_ms = spans[len(spans) // 2]
 
     if rank == 0:
         per_frame = elapsed / n_frames
@@ -339,7 +402,9 @@ def main():
         k_ms = ktimes["tile"]
         achieved = tile_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = json.load(fh).get(args.config, {}).get("k_tile")
@@ -376,6 +441,14 @@ def main():
             "scene_render_ms_host_with_overlay": None if host_overlay_ms is None else round(host_overlay_ms, 4),
             "scene_render_ms_host_same_camera": None if host_same_ms is None else round(host_same_ms, 4),
             "scene_render_ms_host_with_overlay_same_camera": None if host_overlay_same_ms is None else round(host_overlay_same_ms, 4),
+            "scene_render_ms_pipelined": None if pipe_ms is None else round(pipe_ms, 4),
+            "scene_render_ms_pipelined_with_overlay": None if pipe_overlay_ms is None else round(pipe_overlay_ms, 4),
+            "value_protocol": None if not protocol_ms else round(frags_base / protocol_ms / 1e3, 2),
+            "protocol": None if not protocol_ms else {
+                "what": "SURVEY 8(d): one frame at a time, HIP events around mr_render's device section (three kernels + the "
+                        "copy of the uint8 frame into page-locked host memory), median of 32 frames of a moving camera",
+                "ms_per_frame": round(protocol_ms, 5), "ms_copy": round(protocol_copy_ms, 5),
+                "frames_per_s": round(1e3 / protocol_ms, 1)},
             "reference_numpy_mfrag_s": REFERENCE_MFRAGS[args.config],
             "gpu_ms_per_kernel": {k: round(v, 5) for k, v in ktimes.items()},
             "gpu_ms_per_kernel_solo": {k: round(v, 5) for k, v in ktimes_solo.items()},
@@ -394,6 +467,7 @@ def main():
                          "solo_launch_ms": round(ktimes_solo["tile"], 5),
                          "solo_achieved": round(tile_alg / (ktimes_solo["tile"] * 1e-3) / 1e9, 2),
                          "solo_frac": round(tile_alg / (ktimes_solo["tile"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "roofline_valu": valu_roofline(args.config, k_ms, ktimes_solo["tile"]),
         }
         if world == 1 and not args.no_cpu_baseline:
             scene.camera, scene.debug_camera = base_cameras

@@ -120,6 +120,7 @@ struct FrameSlot {
     int last_n_tiles = 0;
     bool last_ordered = false;               // the last frame's tile kernel followed the order buffer (else row-major)
     bool have_frame = false, stats_reduced = false;
+    bool last_copied = false;                // the last frame was followed by a timed device-to-host copy (mr_render, mr_render_async)
 
     void reset_caps() { bins_zeroed_for = 0; have_frame = false; }
     void release()
@@ -711,6 +712,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     fs->last_n_tiles = n_tiles;
     fs->have_frame = true;
     fs->stats_reduced = false;
+    fs->last_copied = false;
     fs->frames_enqueued += 1;
     sc->last = fs;
     return MR_OK;
@@ -1085,7 +1087,7 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
         if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
         if ((rc = fetch_counters(sc, fs, stats != nullptr))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
-        if (!(fr->flags & MR_FRAME_NO_TIMING)) HIP_TRY(hipEventRecord(fs->ev[5], g_stream));
+        if (!(fr->flags & MR_FRAME_NO_TIMING)) { HIP_TRY(hipEventRecord(fs->ev[5], g_stream)); fs->last_copied = true; }
         HIP_TRY(hipStreamSynchronize(g_stream));
         rc = collect(sc, fs, true);
         if (rc == MR_OK) {
@@ -1114,7 +1116,7 @@ int mr_render_async(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, int
     if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
     if ((rc = fetch_counters(sc, fs, (fr->flags & MR_FRAME_COUNTERS) != 0))) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, ln.stream));
-    if (!(fr->flags & MR_FRAME_NO_TIMING)) HIP_TRY(hipEventRecord(fs->ev[5], ln.stream));
+    if (!(fr->flags & MR_FRAME_NO_TIMING)) { HIP_TRY(hipEventRecord(fs->ev[5], ln.stream)); fs->last_copied = true; }
     ln.busy = true;
     return MR_OK;
 }
@@ -1221,9 +1223,9 @@ int mr_get_stats(mr_scene *sc, mr_stats *stats)
         int rc = fetch_counters(sc, s.get(), true);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));
-        if (collect(sc, s.get(), false) == MR_E_OVERFLOW) overflowed = true;
+        if (collect(sc, s.get(), s->last_copied) == MR_E_OVERFLOW) overflowed = true;
     }
-    (void)collect(sc, fs, false);               // report the most recent frame
+    (void)collect(sc, fs, fs->last_copied);     // report the most recent frame
     *stats = sc->stats;
     if (overflowed)
         return fail(MR_E_OVERFLOW, "a frame overflowed a work list (now grown): render it again");
