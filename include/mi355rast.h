@@ -223,6 +223,19 @@ int mr_scene_set_overlay_cameras(mr_scene *scene, const double *corners, const d
  * (row_end - row_begin) x width x 3 bytes, row 0 = top row of the band.  stats may be NULL. */
 int mr_render(mr_scene *scene, const mr_frame_desc *frame, uint8_t *out_rgb, mr_stats *stats);
 
+/* The overlay on a frame split over several devices.  The lines test z at pixels other devices own, so a device that
+ * renders only part of the frame (row_begin / row_end of equal bands, or stripe_count > 1) with MR_FRAME_OVERLAY does not
+ * draw the overlay; it APPENDS the state (z, float colour: 24 bytes) of every touched pixel it owns to its rows, at
+ * offset round_up(bytes of its rows, 16) of d_out_rgb, mr_overlay_state_bytes() bytes in all (the same on every device:
+ * one entry per touched pixel, the owner fills its own).  After the ONE all-gather of rows + state, every device calls
+ * mr_overlay_apply: d_parts holds the `world` parts, part_stride bytes apart, the state at state_offset in each;
+ * `striped` says how the rows were split (interleaved tile rows, else equal bands); d_frame is the assembled uint8
+ * frame (height x width x 3, row 0 = top), whose touched pixels are rewritten.  The result is the frame one device
+ * renders with the overlay on.  Work is enqueued on `stream` (NULL = the library's own). */
+int64_t mr_overlay_state_bytes(mr_scene *scene);
+int mr_overlay_apply(mr_scene *scene, const void *d_parts, int64_t part_stride, int64_t state_offset, int32_t world,
+                     int32_t striped, int32_t system, void *d_frame, void *stream);
+
 /* mr_render in two halves, for frames of a sequence: mr_render_async enqueues the frame and the device-to-host copy
  * of its uint8 rows into out_rgb on one of the scene's MR_ASYNC_LANES lanes (a stream and a set of work buffers
  * each) and returns at once; mr_render_wait blocks until that lane's frame is in out_rgb.  With two lanes the copy

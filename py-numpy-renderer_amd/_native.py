@@ -88,6 +88,8 @@ _PROTOTYPES = {
                                                C.c_int32, C.c_int32, C.c_int32]),
     "mr_scene_set_list_capacities": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "mr_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "mr_overlay_state_bytes": (C.c_int64, [C.c_void_p]),
+    "mr_overlay_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mr_render_async": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int32]),
     "mr_render_wait": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Stats)]),
     "mr_host_alloc": (C.c_void_p, [C.c_uint64]),
@@ -471,12 +473,17 @@ class DeviceRenderer:
         self._last_stats = value
 
     def render_device(self, scene, d_out_ptr, stream_ptr=0, shadows=True, row_band=None, light_timing=False,
-                      counters=False, stripe=None, no_timing=False):
-        """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*."""
+                      counters=False, stripe=None, no_timing=False, overlay=False):
+        """``mr_render_device``: enqueue a frame whose uint8 band lands at device pointer *d_out_ptr*.  With *overlay*
+        a device that renders the whole frame draws the debug frustum; one that renders part of it appends the state of
+        the touched pixels it owns to its rows (``overlay_state_bytes``, ``overlay_apply``)."""
         self.sync_scene(scene)
         self.sync_skybox(scene)
         pf = self.packed_frame(scene, shadows)
-        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters, stripe=stripe, no_timing=no_timing)
+        if overlay:
+            self.sync_overlay(scene)
+        desc = fill_frame_desc(pf, row_band, False, light_timing, counters=counters, stripe=stripe, no_timing=no_timing,
+                               overlay=overlay)
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
         self._frame = (pf.height, pf.width)
@@ -496,6 +503,16 @@ class DeviceRenderer:
         """Re-issue a prepared frame descriptor (no Python-side packing in the timed loop)."""
         _check(self.lib.mr_render_device(self.handle, C.byref(desc), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr)), "mr_render_device")
+
+    def overlay_state_bytes(self):
+        """Bytes a device of a split frame appends to its rows for the overlay (``mr_overlay_state_bytes``)."""
+        return int(_check(self.lib.mr_overlay_state_bytes(self.handle), "mr_overlay_state_bytes"))
+
+    def overlay_apply(self, d_parts_ptr, part_stride, state_offset, world, striped, system, d_frame_ptr, stream_ptr=0):
+        """``mr_overlay_apply``: replay the overlay on the frame assembled from *world* parts."""
+        _check(self.lib.mr_overlay_apply(self.handle, C.c_void_p(d_parts_ptr), int(part_stride), int(state_offset), int(world),
+                                         int(bool(striped)), int(system), C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)),
+               "mr_overlay_apply")
 
     def set_list_capacities(self, small_pairs=0, big_pairs=0, quads=0, work=0):
         """Where the per-tile work lists start (they grow on overflow); a tuning / test hook."""

@@ -417,7 +417,9 @@ class Scene:
         backend = self._backend()
         report = self.verbose and row_band is None
         # the debug camera's frustum, drawn by the device into its own frame and z-buffer right after the
-        # tile kernel (obj/core.py:638); a row band of a multi-GPU split is rendered without it
+        # tile kernel (obj/core.py:638).  A row band of a multi-GPU split cannot draw it alone (the lines test z at
+        # pixels other devices own): multigpu.BandRenderer(overlay=True) gathers the touched pixels' state with
+        # the rows and replays the overlay on the assembled frame
         overlay = self.draw_debug_frustum and row_band is None
         out = backend.render(self, shadows=shadows, row_band=row_band, face_status=report, counters=False,
                              keep_buffers=False, timing=False, overlay=overlay)

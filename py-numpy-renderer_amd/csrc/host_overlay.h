@@ -185,4 +185,24 @@ inline void build_overlay_lists(const double *corners, const int32_t *faces, con
         for (uint64_t m = bits[w]; m; m &= m - 1) out.touched.push_back((int32_t)(w * 64 + (size_t)__builtin_ctzll(m)));
 }
 
+// The overlay's targets as SLOTS of the list of touched pixels (for a frame assembled from several devices: the
+// overlay is then replayed on a compact copy of the touched pixels' state, gathered from the devices that own
+// them): slot_of[k][p] = slot of target k of point p, touched[slot] = pixel, slots in order of first appearance.
+// `stamp` / `value` are frame-sized work arrays kept between calls (generation stamps instead of clears).
+struct OverlaySlotWork { std::vector<uint32_t> stamp, value; uint32_t generation = 0; };
+inline void build_overlay_slots(const int32_t *target /* (5, n_points) */, size_t n_points, size_t n_pixels, OverlaySlotWork &ws,
+                                std::vector<int32_t> &slot_of, std::vector<int32_t> &touched)
+{
+    if (ws.stamp.size() < n_pixels) { ws.stamp.assign(n_pixels, 0u); ws.value.assign(n_pixels, 0u); ws.generation = 0; }
+    if (ws.generation > 0xfffffff0u) { std::fill(ws.stamp.begin(), ws.stamp.end(), 0u); ws.generation = 0; }
+    const uint32_t gen = ++ws.generation;
+    slot_of.resize(5 * n_points);
+    touched.clear();
+    for (size_t i = 0; i < 5 * n_points; ++i) {
+        const size_t pixel = (size_t)target[i];
+        if (ws.stamp[pixel] != gen) { ws.stamp[pixel] = gen; ws.value[pixel] = (uint32_t)touched.size(); touched.push_back((int32_t)pixel); }
+        slot_of[i] = (int32_t)ws.value[pixel];
+    }
+}
+
 }  // namespace mr_host

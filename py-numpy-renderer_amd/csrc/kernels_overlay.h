@@ -199,4 +199,47 @@ k_overlay(const OverlayArgs a, const double sign)
     }
 }
 
+// ---- a frame split over several devices (multigpu.py): the lines' z tests read the z-buffer at pixels other devices
+// own, so the overlay is replayed AFTER the all-gather, on the touched pixels' state, which every device appends to
+// the rows it contributes: OVERLAY_STATE_BYTES per slot of the list of touched pixels, filled in by the device that
+// owns the pixel (k_overlay_export), picked out of the owner's part by k_overlay_import.
+constexpr int OVERLAY_STATE_BYTES = 24;          // z float64, colour 3 x float32, 4 bytes of padding
+struct OverlayState { double z; float f[3]; uint32_t pad; };
+static_assert(sizeof(OverlayState) == OVERLAY_STATE_BYTES, "OverlayState layout");
+
+// which device of the split owns screen row py (y up): contiguous bands of output rows (which count from the top), or
+// interleaved tile rows (include/mi355rast.h, stripe_count)
+__device__ __forceinline__ int overlay_owner(int py, int height, int world, int striped)
+{
+    return striped ? (py / TILE_H) % world : (height - 1 - py) / (height / world);
+}
+
+__global__ void __launch_bounds__(256)
+k_overlay_export(const int32_t *__restrict__ touched, int n_slots, const double *__restrict__ zbuf, const float *__restrict__ frame,
+                 int width, int height, int world, int striped, int rank, OverlayState *__restrict__ state)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_slots) return;
+    const int t = touched[i];
+    if (overlay_owner(t / width, height, world, striped) != rank) return;
+    OverlayState s;
+    s.z = zbuf[t];
+    s.f[0] = frame[(size_t)t * 3]; s.f[1] = frame[(size_t)t * 3 + 1]; s.f[2] = frame[(size_t)t * 3 + 2];
+    s.pad = 0;
+    state[i] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_overlay_import(const int32_t *__restrict__ touched, int n_slots, const char *__restrict__ parts, size_t part_stride,
+                 size_t state_offset, int width, int height, int world, int striped, double *__restrict__ st_z,
+                 float *__restrict__ st_f)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_slots) return;
+    const int owner = overlay_owner(touched[i] / width, height, world, striped);
+    const OverlayState s = reinterpret_cast<const OverlayState *>(parts + (size_t)owner * part_stride + state_offset)[i];
+    st_z[i] = s.z;
+    st_f[3 * i] = s.f[0]; st_f[3 * i + 1] = s.f[1]; st_f[3 * i + 2] = s.f[2];
+}
+
 }  // namespace mr

@@ -189,7 +189,7 @@ struct TileArgs {
     uint32_t *bin_count;          // cursors = list lengths; zeroed again at the end of the tile
     const uint32_t *items[BIN_CLASSES];
     uint32_t cap[BIN_CLASSES];
-    const uint8_t *tap_mask;      // [n_tiles] or null: only the tiles marked here write the taps below (the overlay's tiles)
+    const uint8_t *tap_mask;      // [tiles of the whole frame] or null: only the tiles marked here write the taps below (the overlay's tiles)
     double *zbuf;                 // optional taps (MR_FRAME_KEEP_BUFFERS): may be null
     int32_t *winner, *stencil;
     uint32_t *tile_stats;
@@ -289,7 +289,7 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         // the host has finalised already, or the skybox (no lists to walk, no barriers but the gamma table's).
         // Shadow quads over it only matter to the counters.
         const bool sky_tile = (fc.flags & MR_FRAME_SKYBOX) && sh.sky;
-        taps = (sh.frame || ta.zbuf) && (!ta.tap_mask || ta.tap_mask[tile]);
+        taps = (sh.frame || ta.zbuf) && (!ta.tap_mask || ta.tap_mask[tile_row_frame(fc, ltr) * fc.tiles_x + tile % fc.tiles_x]);
         if (n_small_raw == 0 && n_big_raw == 0 && (n_quad_raw == 0 || !counters) && (sky_tile || (fc.background_u8 >> 24)) &&
             !taps) {
             if (part != 0) return;                        // (a tile that was heavy a frame ago: one part will do)

@@ -110,7 +110,8 @@ struct FrameSlot {
         DevBuf lists, scratch;
         void *staging = nullptr;
         size_t staging_cap = 0;
-        size_t off[4] = {};                  // byte offsets of z, targets, segments, tile mask in `lists`
+        size_t off[6] = {};                  // byte offsets of z, targets, segments, tile mask (+ slot ids, touched pixels) in `lists`
+        bool with_slots = false;             // `lists` also holds the slot lists of a split frame
         size_t state_entries = 0;            // entries of win / any in `scratch` (zero between frames)
         uint64_t serial = 0;                 // the scene's ov_serial this copy holds
         hipEvent_t copied = nullptr;         // the last copy out of the staging buffer
@@ -181,6 +182,11 @@ struct mr_scene {
     std::vector<double> ov_z;
     std::vector<int32_t> ov_seg;             // first point, number of points per segment
     std::vector<uint8_t> ov_tile_mask;       // the 16x16 tiles that hold a target
+    // the same targets as slots of the list of touched pixels, for a frame assembled from several devices (built
+    // when first asked for: build_overlay_slots)
+    std::vector<int32_t> ov_slot_of, ov_touched;
+    uint64_t ov_slots_serial = 0;            // the ov_serial the slot lists were built for
+    mr_host::OverlaySlotWork ov_slot_work;
     DevBuf d_sky;                            // cubemap texels, uint8 (6, S, S, 3)
     DevBuf d_gamma;                          // GAMMA_LUT_SIZE float32 thresholds of the finalise step function
     int32_t sky_size = 0;
@@ -454,13 +460,25 @@ void fill_overlay_args(const mr_scene *sc, const FrameSlot *fs, mr::OverlayArgs 
 // and copied with ONE asynchronous copy on the slot's stream (behind the slot's earlier frames, which read the old
 // lists, and in front of the frame that needs the new ones).  The staging buffer is rewritten only after the copy
 // that last read it has completed (an event; mr_render and mr_render_wait have drained the stream long before).
-int sync_slot_overlay(mr_scene *sc, FrameSlot *fs)
+void ensure_overlay_slots(mr_scene *sc)
 {
-    if (fs->ov.serial == sc->ov_serial || sc->ov_points == 0) return MR_OK;
-    const void *src[4] = { sc->ov_z.data(), sc->ov_target.data(), sc->ov_seg.data(), sc->ov_tile_mask.data() };
-    const size_t bytes[4] = { sc->ov_z.size() * 8, sc->ov_target.size() * 4, sc->ov_seg.size() * 4, sc->ov_tile_mask.size() };
+    if (sc->ov_slots_serial == sc->ov_serial) return;
+    mr_host::build_overlay_slots(sc->ov_target.data(), (size_t)sc->ov_points, (size_t)sc->ov_height * sc->ov_width, sc->ov_slot_work,
+                                 sc->ov_slot_of, sc->ov_touched);
+    sc->ov_slots_serial = sc->ov_serial;
+}
+
+int sync_slot_overlay(mr_scene *sc, FrameSlot *fs, bool with_slots = false)
+{
+    if (sc->ov_points == 0 || (fs->ov.serial == sc->ov_serial && (fs->ov.with_slots || !with_slots))) return MR_OK;
+    if (with_slots) ensure_overlay_slots(sc);
+    const int n_src = with_slots ? 6 : 4;
+    const void *src[6] = { sc->ov_z.data(), sc->ov_target.data(), sc->ov_seg.data(), sc->ov_tile_mask.data(),
+                           sc->ov_slot_of.data(), sc->ov_touched.data() };
+    const size_t bytes[6] = { sc->ov_z.size() * 8, sc->ov_target.size() * 4, sc->ov_seg.size() * 4, sc->ov_tile_mask.size(),
+                              with_slots ? sc->ov_slot_of.size() * 4 : 0, with_slots ? sc->ov_touched.size() * 4 : 0 };
     size_t total = 0;
-    for (int i = 0; i < 4; ++i) { fs->ov.off[i] = total; total += (bytes[i] + 15) & ~(size_t)15; }
+    for (int i = 0; i < 6; ++i) { fs->ov.off[i] = total; total += (bytes[i] + 15) & ~(size_t)15; }
     // scratch: win and any (one word per pixel of the frame each, zero between segments and frames)
     const size_t entries = (size_t)sc->ov_height * sc->ov_width;
     const size_t scratch = entries * 8 + (size_t)sc->ov_points + 16;
@@ -474,7 +492,7 @@ int sync_slot_overlay(mr_scene *sc, FrameSlot *fs)
     }
     if (!fs->ov.copied) HIP_TRY(hipEventCreateWithFlags(&fs->ov.copied, hipEventDisableTiming));
     else HIP_TRY(hipEventSynchronize(fs->ov.copied));
-    for (int i = 0; i < 4; ++i) std::memcpy(static_cast<char *>(fs->ov.staging) + fs->ov.off[i], src[i], bytes[i]);
+    for (int i = 0; i < n_src; ++i) std::memcpy(static_cast<char *>(fs->ov.staging) + fs->ov.off[i], src[i], bytes[i]);
     HIP_TRY(fs->ov.lists.ensure(total));
     {
         const void *had = fs->ov.scratch.p;
@@ -487,6 +505,7 @@ int sync_slot_overlay(mr_scene *sc, FrameSlot *fs)
     HIP_TRY(hipMemcpyAsync(fs->ov.lists.p, fs->ov.staging, total, hipMemcpyHostToDevice, fs->stream));
     HIP_TRY(hipEventRecord(fs->ov.copied, fs->stream));
     fs->ov.serial = sc->ov_serial;
+    fs->ov.with_slots = with_slots;
     return MR_OK;
 }
 
@@ -503,12 +522,16 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     // did the caller ask for the z / stencil / winner / float-frame taps?  (The overlay needs z and colour too, but
     // only at the pixels its lines touch: then only the tiles that hold such a pixel write them, ov_off[7].)
     const bool taps_asked = (fc.flags & (MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT)) != 0;
+    // a device that owns only part of the frame (a rank of a multi-GPU split) cannot replay the overlay: its lines test
+    // z at pixels other devices own.  It appends the state of the touched pixels it owns to its rows instead
+    // (k_overlay_export), and the overlay is replayed on the assembled frame (mr_overlay_apply).
+    const bool partial = fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1;
     if (fc.flags & MR_FRAME_OVERLAY) {
-        if (fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1)
-            return fail(MR_E_INVALID, "the debug-frustum overlay needs the whole frame on one device (no row band, no stripes)");
+        if (partial && fr->stripe_count <= 1 && (fr->height % (fr->row_end - fr->row_begin) || fr->row_begin % (fr->row_end - fr->row_begin)))
+            return fail(MR_E_INVALID, "overlay on a row band: the bands of the split must be equal");
         if (sc->ov_points > 0 && (sc->ov_width != fc.width || sc->ov_height != fc.height))
             return fail(MR_E_INVALID, "overlay lists were built for a frame of another size");
-        if (overlay && (rc = sync_slot_overlay(sc, fs))) return rc;
+        if (overlay && (rc = sync_slot_overlay(sc, fs, partial))) return rc;
         fc.flags |= MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT;
     }
     const size_t npx = (size_t)fc.width * fc.height;
@@ -697,7 +720,15 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
                            fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(), fs->d_clips.as<TriClip>(),
                            fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>());
-    if (overlay) {                          // after the lit pass' per-face verdicts, as in obj/core.py:624-638
+    if (overlay && partial) {
+        const int world = fr->stripe_count > 1 ? fr->stripe_count : fr->height / (fr->row_end - fr->row_begin);
+        const int rank = fr->stripe_count > 1 ? fr->stripe_index : fr->row_begin / (fr->row_end - fr->row_begin);
+        const int n_slots = (int)sc->ov_touched.size();
+        OverlayState *state = reinterpret_cast<OverlayState *>(d_out + ((out_bytes(fr) + 15) & ~(size_t)15));
+        hipLaunchKernelGGL(k_overlay_export, dim3(blocks_for(n_slots, 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const int32_t *>(static_cast<const char *>(fs->ov.lists.p) + fs->ov.off[5]), n_slots,
+                           fs->d_z.as<double>(), fs->d_frame.as<float>(), fc.width, fc.height, world, fr->stripe_count > 1 ? 1 : 0, rank, state);
+    } else if (overlay) {                   // after the lit pass' per-face verdicts, as in obj/core.py:624-638
         OverlayArgs oa;
         fill_overlay_args(sc, fs, oa);
         // on the frame's own z-buffer and float frame (so the debug taps show them after the overlay, like upstream's)
@@ -1135,6 +1166,59 @@ int mr_render_wait(mr_scene *sc, int32_t lane, mr_stats *stats)
     if (stats) *stats = sc->stats;
     if (rc == MR_E_OVERFLOW) return fail(MR_E_OVERFLOW, "the frame overflowed a work list (now grown): render it again");
     return rc;
+}
+
+int64_t mr_overlay_state_bytes(mr_scene *sc)
+{
+    if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    if (sc->ov_points == 0) return 0;
+    ensure_overlay_slots(sc);
+    return (int64_t)sc->ov_touched.size() * mr::OVERLAY_STATE_BYTES;
+}
+
+int mr_overlay_apply(mr_scene *sc, const void *d_parts, int64_t part_stride, int64_t state_offset, int32_t world, int32_t striped,
+                     int32_t system, void *d_frame, void *stream_)
+{
+    using namespace mr;
+    if (!sc || !d_parts || !d_frame) return fail(MR_E_INVALID, "NULL argument");
+    if (world < 1 || part_stride <= 0 || state_offset < 0 || (system != 1 && system != -1)) return fail(MR_E_INVALID, "mr_overlay_apply: bad argument");
+    if (sc->ov_points == 0) return MR_OK;
+    if (!striped && sc->ov_height % world) return fail(MR_E_INVALID, "mr_overlay_apply: the bands of the split must be equal");
+    int rc = ensure_init();
+    if (rc) return rc;
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : g_stream;
+    FrameSlot *fs = slot_for(sc, stream);
+    if (!fs) return fail(MR_E_DEVICE, "out of frame slots");
+    if ((rc = sync_slot_overlay(sc, fs, true))) return rc;
+    const int n_slots = (int)sc->ov_touched.size();
+    // the compact state and the bidding words, per slot of the list of touched pixels (the words zero between frames)
+    {
+        const size_t need = (size_t)n_slots * (8 + 12 + 4 + 4) + (size_t)sc->ov_points + 64;
+        const void *had = fs->d_vclip.p;           // (a buffer this path owns: the matrix-core vertex path does not run on assembled frames)
+        HIP_TRY(fs->d_vclip.ensure(need));
+        if (fs->d_vclip.p != had) HIP_TRY(hipMemsetAsync(fs->d_vclip.p, 0, fs->d_vclip.cap, stream));
+    }
+    char *scratch = static_cast<char *>(fs->d_vclip.p);
+    OverlayArgs oa;
+    const char *base = static_cast<const char *>(fs->ov.lists.p);
+    oa.z = reinterpret_cast<const double *>(base + fs->ov.off[0]);
+    oa.idx = reinterpret_cast<const int32_t *>(base + fs->ov.off[4]);
+    oa.seg = reinterpret_cast<const int32_t *>(base + fs->ov.off[2]);
+    oa.pixel_of = reinterpret_cast<const int32_t *>(base + fs->ov.off[5]);
+    oa.n_points = sc->ov_points; oa.n_segments = sc->ov_segments;
+    oa.st_z = reinterpret_cast<double *>(scratch);
+    oa.st_f = reinterpret_cast<float *>(scratch + (size_t)n_slots * 8);
+    oa.win = reinterpret_cast<uint32_t *>(scratch + (size_t)n_slots * 20);
+    oa.any = oa.win + n_slots;
+    oa.keep = reinterpret_cast<uint8_t *>(oa.any + n_slots);
+    oa.out = static_cast<uint8_t *>(d_frame); oa.out_width = sc->ov_width; oa.out_height = sc->ov_height;
+    oa.gamma_lut = sc->d_gamma.as<float>();
+    hipLaunchKernelGGL(k_overlay_import, dim3(blocks_for(n_slots, 256)), dim3(256), 0, stream, oa.pixel_of, n_slots,
+                       static_cast<const char *>(d_parts), (size_t)part_stride, (size_t)state_offset, sc->ov_width, sc->ov_height,
+                       world, striped ? 1 : 0, oa.st_z, oa.st_f);
+    hipLaunchKernelGGL(k_overlay, dim3(1), dim3(OVERLAY_BLOCK), 0, stream, oa, (double)system);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
 }
 
 void *mr_host_alloc(uint64_t bytes)

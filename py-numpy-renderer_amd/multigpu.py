@@ -99,7 +99,7 @@ class BandRenderer:
     """
 
     def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False, frames_in_flight=1,
-                 partition="bands", timing_every=1):
+                 partition="bands", timing_every=1, overlay=False):
         height, width = (int(v) for v in scene.resolution)
         if partition not in ("bands", "stripes"):
             raise ValueError(f"unknown partition {partition!r}")
@@ -114,15 +114,34 @@ class BandRenderer:
         self.stripe = (rank, world) if striped else None
         self.band = (0, height) if striped else row_band(height, rank, world)
         rows = stripe_rows(height, world) if striped else self.band[1] - self.band[0]
+        # The debug-frustum overlay (obj/core.py:638) of a split frame: every rank appends the state (z, float colour)
+        # of the touched pixels it owns to its rows, the ONE all-gather carries rows and state, and every rank replays
+        # the overlay on the assembled frame (include/mi355rast.h, mr_overlay_apply): the lines test z at pixels other
+        # ranks own, so no rank could draw its share alone.  On one device the frame's own kernel draws it.
+        self.overlay = bool(overlay)
+        self.rows_bytes = rows * width * 3
+        self.state_offset = self.state_bytes = 0
+        if self.overlay and world > 1:
+            self.backend.sync_scene(scene)
+            self.backend.sync_overlay(scene)
+            self.state_offset = -(-self.rows_bytes // 16) * 16
+            self.state_bytes = -(-self.backend.overlay_state_bytes() // 16) * 16
+        self.part_bytes = self.state_offset + self.state_bytes if self.state_bytes else self.rows_bytes
         self.lanes = []
         self.count = 0
         self.descs = []
         for _ in range(max(1, int(frames_in_flight))):
             stream = torch.cuda.Stream()
             frame = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
-            part = frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
-            gathered = torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda") if striped else frame
+            if self.state_bytes:            # rows + state travel as one flat buffer; the rows are copied out after the gather
+                part = torch.zeros(self.part_bytes, dtype=torch.uint8, device="cuda")
+                gathered = torch.empty(self.part_bytes * world, dtype=torch.uint8, device="cuda")
+            else:
+                part = frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
+                gathered = torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda") if striped else frame
             self.lanes.append((stream, frame, part, gathered))
+        self.rows_all = (torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda")
+                         if self.state_bytes and striped else None)
         self.index = unstripe_index(height, world, "cuda") if striped else None
         # the collective's operands, flattened once (step() is the host's per-frame cost: keep it to the calls)
         self._flat = [(g.view(-1), p.view(-1)) for _, _, p, g in self.lanes]
@@ -140,7 +159,8 @@ class BandRenderer:
                 with torch.cuda.stream(stream):
                     self.desc = self.backend.render_device(self.scene, part.data_ptr(), stream.cuda_stream,
                                                            shadows=self.shadows, row_band=self.band,
-                                                           light_timing=self.light_timing, stripe=self.stripe)
+                                                           light_timing=self.light_timing, stripe=self.stripe,
+                                                           overlay=self.overlay)
                 stream.synchronize()
             if not self.backend.overflowed():
                 self.set_descriptors([self.desc])
@@ -169,10 +189,24 @@ class BandRenderer:
                     dist.all_gather_into_tensor(gflat, pflat)
                 else:
                     all_gather_frame(part, gathered)
-                if self.index is not None:
+                if self.state_bytes:
+                    self._assemble_with_overlay(gathered, frame, stream)
+                elif self.index is not None:
                     unstripe(gathered, self.height, self.world, out=frame, index=self.index)
         self.frame = frame
         return frame
+
+    def _assemble_with_overlay(self, gathered, frame, stream):
+        """Rows out of the gathered parts into *frame*, then the overlay replayed on it from the gathered state."""
+        parts = gathered.view(self.world, self.part_bytes)
+        rows = parts[:, :self.rows_bytes]
+        if self.index is None:              # bands in output order: the rows of rank r are rows r * H/N ... of the frame
+            frame.view(self.world, self.rows_bytes).copy_(rows)
+        else:
+            self.rows_all.view(self.world, self.rows_bytes).copy_(rows)
+            unstripe(self.rows_all, self.height, self.world, out=frame, index=self.index)
+        self.backend.overlay_apply(gathered.data_ptr(), self.part_bytes, self.state_offset, self.world, self.index is not None,
+                                   int(self.scene.system), frame.data_ptr(), stream.cuda_stream)
 
     def verify(self):
         """Synchronise and check that no frame since the last check overflowed a work list.  Returns

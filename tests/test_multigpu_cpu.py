@@ -102,3 +102,67 @@ def test_ranks_render_their_tiles_and_gather_the_golden_frame(api, oracle_mod, t
         assert frame.shape == g["out"].shape
         assert np.abs(frame.astype(int) - g["out"].astype(int)).max() <= 1, f"rank {rank}"
     assert np.array_equal(np.load(tmp_path / "rank0.npy"), np.load(tmp_path / f"rank{world - 1}.npy"))
+
+
+def _overlay_worker(rank, world, port, name, partition, result_dir):
+    """One rank of a split frame with upstream's default overlay, on the CPU: the oracle renders the rank's rows, the
+    rank appends the state (z, float colour) of the touched pixels it owns, ONE all-gather carries rows and state,
+    and the overlay is replayed on the assembled frame from the gathered state (what mr_overlay_apply does, restated
+    in NumPy: frustums.replay_bids on slots of the list of touched pixels)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from oracle import oracle
+        from py_numpy_renderer_amd._pack import pack_scene
+        from py_numpy_renderer_amd.frustums import OverlayOps, replay_bids
+        scene = scenes.build(scenes.product_api(), name)
+        height, width = (int(v) for v in scene.resolution)
+        packed = pack_scene(scene, shadows=True)
+        if partition == "bands":
+            band = row_band(height, rank, world)
+            mine = oracle.render_packed(packed, own_rows=band, want_status=False, want_silhouette=False)
+            rows = np.ascontiguousarray(mine.out[band[0]:band[1]])
+            owner = lambda py: (height - 1 - py) // (height // world)
+        else:
+            mine = oracle.render_packed(packed, own_stripe=(rank, world), want_status=False, want_silhouette=False)
+            rows = stripe_pack(mine.out, rank, world)
+            owner = lambda py: (py // 16) % world
+        ops = OverlayOps(scene.camera, scene.debug_camera, scene.resolution, native=False)
+        touched, inverse = np.unique(ops.target, return_inverse=True)
+        state = np.zeros(len(touched), dtype=[("z", "<f8"), ("f", "<f4", 3), ("pad", "<u4")])
+        own = owner(touched // width) == rank
+        state["z"][own] = mine.z.reshape(-1)[touched[own]]
+        state["f"][own] = mine.frame.reshape(-1, 3)[touched[own]]
+        offset = -(-rows.size // 16) * 16
+        part = np.zeros(offset + state.nbytes, np.uint8)
+        part[:rows.size] = rows.reshape(-1)
+        part[offset:] = state.view(np.uint8)
+        gathered = all_gather_frame(torch.from_numpy(part)).numpy().reshape(world, -1)
+        parts = torch.from_numpy(np.ascontiguousarray(gathered[:, :rows.size]).reshape((world * rows.shape[0],) + rows.shape[1:]))
+        frame = (parts if partition == "bands" else unstripe(parts, height, world)).numpy().copy()
+        states = np.ascontiguousarray(gathered[:, offset:]).view(state.dtype).reshape(world, len(touched))
+        mine_of = states[owner(touched // width), np.arange(len(touched))]
+        st_z, st_f = mine_of["z"].copy(), mine_of["f"].copy()
+        slots = SimpleNamespace(seg_first=ops.seg_first, seg_count=ops.seg_count, z=ops.z, target=inverse.reshape(ops.target.shape))
+        replay_bids(slots, st_f, st_z, int(scene.system))
+        frame[height - 1 - touched // width, touched % width] = (st_f ** np.float32(0.8) * 255).astype(np.uint8)
+        np.save(os.path.join(result_dir, f"rank{rank}.npy"), frame)
+        np.save(os.path.join(result_dir, f"z{rank}.npy"), np.stack([touched.astype(np.float64), st_z]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partition,world", [("bands", 2), ("stripes", 3)])
+def test_split_frame_with_overlay_gathers_the_golden_overlay_frame(api, oracle_mod, tmp_path, partition, world):
+    """The overlay of a split frame (one all-gather of rows + touched-pixel state, replay on the assembled frame)
+    against the reference's capture with the overlay left on: frame +-1, post-overlay z at the touched pixels bit-exact."""
+    name = "diablo_small_overlay"                    # 240 rows
+    g, _ = load_golden(name)
+    mp.spawn(_overlay_worker, args=(world, _free_port(), name[:-len("_overlay")], partition, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        frame = np.load(tmp_path / f"rank{rank}.npy")
+        assert np.abs(frame.astype(int) - g["out"].astype(int)).max() <= 1, f"rank {rank}"
+        touched, z = np.load(tmp_path / f"z{rank}.npy")
+        assert np.array_equal(z.view(np.uint64), g["z_overlay"].reshape(-1)[touched.astype(np.int64)].view(np.uint64)), f"rank {rank}"
+    assert np.array_equal(np.load(tmp_path / "rank0.npy"), np.load(tmp_path / f"rank{world - 1}.npy"))

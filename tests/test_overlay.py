@@ -165,3 +165,46 @@ def test_device_scheme_replays_like_the_statement_lists():
         assert not np.array_equal(za, z0)
         points += ops.n_points
     assert points > 5000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition,world", [("bands", 2), ("bands", 3), ("stripes", 2), ("stripes", 3), ("stripes", 5)])
+@pytest.mark.parametrize("name", scenes.OVERLAY)
+def test_split_frame_with_overlay_equals_the_single_device_frame(api, name, partition, world):
+    """A frame split over N devices with upstream's default overlay: every rank appends the state (z, float colour) of
+    the touched pixels it owns to its rows, the parts are gathered, and the overlay is replayed on the assembled frame
+    (mr_overlay_apply) -- the lines test z at pixels other ranks own, so no rank could draw its share alone.  Here one
+    GPU plays every rank in turn; the assembled frame must be, byte for byte, the frame one device renders with the
+    overlay on (which the reference captures pin)."""
+    import torch
+    from py_numpy_renderer_amd.multigpu import row_band, stripe_rows, unstripe
+    scene = scenes.build(api, name[:-len("_overlay")])
+    scene.draw_debug_frustum = True
+    want = scene.render().copy()
+    h, w = (int(v) for v in scene.resolution)
+    if partition == "bands" and h % world:
+        pytest.skip("rows do not split evenly")
+    backend = scene._backend()
+    striped = partition == "stripes"
+    rows = stripe_rows(h, world) if striped else h // world
+    rows_bytes = rows * w * 3
+    offset = -(-rows_bytes // 16) * 16
+    state = -(-backend.overlay_state_bytes() // 16) * 16
+    assert state > 0
+    part_bytes = offset + state
+    gathered = torch.zeros(world * part_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(world):
+        backend.render_device(scene, gathered.data_ptr() + r * part_bytes, 0, shadows=True, no_timing=True, overlay=True,
+                              row_band=None if striped else row_band(h, r, world), stripe=(r, world) if striped else None)
+    assert not backend.overflowed()                       # (synchronises)
+    parts = gathered.view(world, part_bytes)[:, :rows_bytes].contiguous().view(world * rows, w, 3)
+    frame = unstripe(parts, h, world) if striped else parts.clone()
+    plain = frame.cpu().numpy().copy()
+    torch.cuda.synchronize()
+    backend.overlay_apply(gathered.data_ptr(), part_bytes, offset, world, striped, int(scene.system), frame.data_ptr(), 0)
+    backend.overflowed()
+    got = frame.cpu().numpy()
+    assert (got != plain).any(), "the overlay drew nothing"
+    assert np.array_equal(got, want)
+    scene.close()
