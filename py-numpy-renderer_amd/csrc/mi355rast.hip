@@ -1109,6 +1109,9 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     if ((rc = ensure_init())) return rc;
     FrameSlot *fs = slot_for(sc, g_stream);
     if (!fs) return fail(MR_E_DEVICE, "out of frame slots");
+    if ((fr->flags & MR_FRAME_OVERLAY) && (fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1))
+        return fail(MR_E_INVALID, "the overlay of a frame split over devices is drawn on the assembled whole frame: render the "
+                                  "part with mr_render_device (which appends the touched pixels' state), then mr_overlay_apply");
     mr_frame_desc counted = *fr;
     if (stats) counted.flags |= MR_FRAME_COUNTERS;         // whoever asks for the counters gets them
     fr = &counted;
@@ -1137,6 +1140,8 @@ int mr_render_async(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, int
     int rc = validate_frame(fr);
     if (rc) return rc;
     if ((rc = ensure_init())) return rc;
+    if ((fr->flags & MR_FRAME_OVERLAY) && (fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1))
+        return fail(MR_E_INVALID, "the overlay of a frame split over devices is drawn on the assembled whole frame (mr_overlay_apply)");
     mr_scene::Lane &ln = sc->lanes[lane];
     if (ln.busy) return fail(MR_E_INVALID, "this lane still has a frame in flight: mr_render_wait first");
     if (!ln.stream) HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));

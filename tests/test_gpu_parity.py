@@ -309,7 +309,7 @@ def test_errors_are_loud(api):
     scene.close()
     scene = scenes.build(api, "cube_small")
     backend = scene._backend()
-    with pytest.raises(RuntimeError, match="whole frame"):
+    with pytest.raises(RuntimeError, match="whole frame"):      # a part of a split frame: mr_render_device + mr_overlay_apply
         backend.render(scene, row_band=(0, 60), overlay=True)
     scene.close()
 
