@@ -95,6 +95,51 @@ k_edge_compact(int n_edges, const EdgeRec *__restrict__ edges, EdgeRec32 *__rest
     out[e] = c;
 }
 
+// The static face records (rast_types.h, FacePosT / FaceAttr): one gather per scene, when it is committed.
+template <class T>
+__global__ void __launch_bounds__(256)
+k_face_static(int n_faces, const int32_t *__restrict__ faces, const uint8_t *__restrict__ face_flags,
+              const double *__restrict__ verts, const float *__restrict__ uv, const float *__restrict__ normals,
+              FacePosT<T> *__restrict__ out_pos, FaceAttr *__restrict__ out_attr)
+{
+    const int f = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (f >= n_faces) return;
+    const int32_t *row = faces + (size_t)f * 12;           // [vertex, uv, normal, material] per corner
+    const uint8_t ff = face_flags[f];
+    FacePosT<T> p;
+    FaceAttr a;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p.v[k][j] = (T)verts[(size_t)row[k * 4] * 4 + j];
+        a.uv[k][0] = (ff & FF_HAS_UV) ? uv[(size_t)row[k * 4 + 1] * 3] : 0.f;
+        a.uv[k][1] = (ff & FF_HAS_UV) ? uv[(size_t)row[k * 4 + 1] * 3 + 1] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a.n[k][j] = (ff & FF_HAS_NORMALS) ? normals[(size_t)row[k * 4 + 2] * 3 + j] : 0.f;
+    }
+    p.material = row[3]; p.flags = ff; p.pad[0] = p.pad[1] = 0;
+    a.pad = 0.f;
+    out_pos[f] = p;
+    out_attr[f] = a;
+}
+
+// The three corners of face f (and its material and flags) from the static records, as float64
+__device__ __forceinline__ void load_face_pos(const void *face_pos, bool pos32, int f, double va[4], double vb[4], double vc[4],
+                                              int32_t &material, uint8_t &ff)
+{
+    if (pos32) {
+        const FacePos32 p = static_cast<const FacePos32 *>(face_pos)[f];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = (double)p.v[0][j]; vb[j] = (double)p.v[1][j]; vc[j] = (double)p.v[2][j]; }
+        material = p.material; ff = (uint8_t)p.flags;
+    } else {
+        const FacePos64 p = static_cast<const FacePos64 *>(face_pos)[f];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = p.v[0][j]; vb[j] = p.v[1][j]; vc[j] = p.v[2][j]; }
+        material = p.material; ff = (uint8_t)p.flags;
+    }
+}
+
 // One face corner through obj/triangular.py:36-45: clip = v @ MVP (and @ debug MVP), depth =
 // 1 / clip.w, ndc = clip * depth, screen = ndc @ viewport; plus linearize_z of the screen z.
 struct CornerOut {
@@ -248,8 +293,8 @@ struct SetupArgs {
     const float *uv, *normals;
     const VertexOut *vout;           // PRE_XFORM only: what k_vertex_mfma left
     const VertexClip *vclip;
+    const void *face_pos;            // static per face: FacePos32[] / FacePos64[] (fc.pos32)
     TriRec *tris;
-    TriAttr *attrs;
     TriClip *clips;
     uint8_t *status;
     uint32_t *count_list;            // faces whose survivor count needs a wavefront (k_bin_work)
@@ -273,7 +318,7 @@ struct SetupKernArgs { FrameConst fc; SetupArgs sa; BinArgs bins; uint32_t face_
 
 struct CornerOut;
 template <bool PRE_XFORM>
-__device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int4 &ib, const int4 &ic, uint8_t ff,
+__device__ __forceinline__ int tri_setup_record(int f, int32_t material, uint8_t ff,
                                                 const double va[4], const double vb[4], const double vc[4],
                                                 const CornerOut &A, const CornerOut &B, const CornerOut &C,
                                                 unsigned int &covered, PrimBox &pb, bool &clip);
@@ -284,21 +329,19 @@ __device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int
 template <bool PRE_XFORM>
 __device__ __forceinline__ int tri_setup_one(int f, unsigned int &covered, PrimBox &pb, bool &clip)
 {
-    SETUP_ARGS();                                                // phase 1: index row, corners, transform, cull
-    const int4 *row = reinterpret_cast<const int4 *>(sa.faces + (size_t)f * 12);
-    const int4 ia = row[0], ib = row[1], ic = row[2];          // [vertex, uv, normal, material] per corner
-    const uint8_t ff = sa.face_flags[f];
-    const double *wa = sa.verts + (size_t)ia.x * 4, *wb = sa.verts + (size_t)ib.x * 4, *wc = sa.verts + (size_t)ic.x * 4;
-
-    const double va[4] = { wa[0], wa[1], wa[2], wa[3] }, vb[4] = { wb[0], wb[1], wb[2], wb[3] },
-                 vc[4] = { wc[0], wc[1], wc[2], wc[3] };
+    SETUP_ARGS();                                                // phase 1: the face's static record, transform, cull
+    double va[4], vb[4], vc[4];
+    int32_t material;
+    uint8_t ff;
+    load_face_pos(sa.face_pos, fc.pos32 != 0, f, va, vb, vc, material, ff);
     CornerOut A, B, C;
     if (PRE_XFORM) {
+        const int32_t *row = sa.faces + (size_t)f * 12;        // (the matrix-core vertex path goes by vertex index)
         auto take = [&](int v, CornerOut &o) {
             const VertexOut q = sa.vout[v];
             o.sx = q.sx; o.sy = q.sy; o.sz = q.sz; o.depth = q.depth; o.zlin = q.zlin; o.safe = q.safe != 0;
         };
-        take(ia.x, A); take(ib.x, B); take(ic.x, C);
+        take(row[0], A); take(row[4], B); take(row[8], C);
     } else {
         xform_vertex(fc, va, A); xform_vertex(fc, vb, B); xform_vertex(fc, vc, C);
     }
@@ -325,12 +368,12 @@ __device__ __forceinline__ int tri_setup_one(int f, unsigned int &covered, PrimB
         if (cull) { status[f] = FACE_BACK_FACE_CULLING; return 0; }
     }
 
-    return tri_setup_record<PRE_XFORM>(f, ia, ib, ic, ff, va, vb, vc, A, B, C, covered, pb, clip);
+    return tri_setup_record<PRE_XFORM>(f, material, ff, va, vb, vc, A, B, C, covered, pb, clip);
 }
 
 // second half of tri_setup_one: the faces that survive the cull (its own view of the arguments: phase 2)
 template <bool PRE_XFORM>
-__device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int4 &ib, const int4 &ic, uint8_t ff,
+__device__ __forceinline__ int tri_setup_record(int f, int32_t material, uint8_t ff,
                                                 const double va[4], const double vb[4], const double vc[4],
                                                 const CornerOut &A, const CornerOut &B, const CornerOut &C,
                                                 unsigned int &covered, PrimBox &pb, bool &clip)
@@ -363,8 +406,9 @@ __device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int
     if (den == 0) { status[f] = FACE_EMPTY_B; return 0; }
     t.inv_den = 1.0f / den;
     t.zl0 = A.zlin; t.zl1 = B.zlin; t.zl2 = C.zlin;
-    t.material = ia.w;
+    t.material = material;
     t.pad = 0;
+    t.dp[0] = A.depth; t.dp[1] = B.depth; t.dp[2] = C.depth; t.pad2 = 0.0;
     long long box = (long long)(bx1 - bx0) * (long long)(by1 - by0);
     const bool need_clip = (ff & FF_CLIP) && !(A.safe && B.safe && C.safe);
     clip = need_clip;
@@ -394,28 +438,13 @@ __device__ __forceinline__ int tri_setup_record(int f, const int4 &ia, const int
         covered = 0;
         if (found == 1) t.flags |= TF_SINGLE_Z;
     }
-    sa.tris[f] = t;
-
-    // shading attributes, gathered once per face (the corners' world positions are in registers)
-    TriAttr at;
-    at.dp[0] = dp[0]; at.dp[1] = dp[1]; at.dp[2] = dp[2];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { at.world[0][j] = va[j]; at.world[1][j] = vb[j]; at.world[2][j] = vc[j]; }
-    const int ti[3] = { ia.y, ib.y, ic.y }, ni[3] = { ia.z, ib.z, ic.z };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (ff & FF_HAS_UV) { at.uv[k][0] = sa.uv[(size_t)ti[k] * 3]; at.uv[k][1] = sa.uv[(size_t)ti[k] * 3 + 1]; }
-        else at.uv[k][0] = at.uv[k][1] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) at.n[k][j] = (ff & FF_HAS_NORMALS) ? sa.normals[(size_t)ni[k] * 3 + j] : 0.f;
-    }
-    at.pad[0] = at.pad[1] = at.pad[2] = 0.f;
-    sa.attrs[f] = at;
+    sa.tris[f] = t;        // (shading finds the rest of the face -- world corners, uv, normals -- in the static records)
 
     if (need_clip) {
         TriClip &cl = sa.clips[f];
         if (PRE_XFORM) {
-            const VertexClip ca = sa.vclip[ia.x], cb = sa.vclip[ib.x], cc = sa.vclip[ic.x];
+            const int32_t *row = sa.faces + (size_t)f * 12;
+            const VertexClip ca = sa.vclip[row[0]], cb = sa.vclip[row[4]], cc = sa.vclip[row[8]];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 cl.clip[0][j] = ca.clip[j]; cl.clip[1][j] = cb.clip[j]; cl.clip[2][j] = cc.clip[j];
@@ -477,7 +506,7 @@ __device__ __forceinline__ void tri_setup_block(uint32_t block)
 // or a per-fragment clip test).
 __device__ __forceinline__ void
 tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, TriRec *__restrict__ tris,
-               const TriAttr *__restrict__ attrs, const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
+               const TriClip *__restrict__ clips, uint8_t *__restrict__ status,
                Counters *__restrict__ ctr, uint32_t block, uint32_t n_blocks)
 {
     // one wavefront per listed face, 64 samples per step, starting at the chunk that holds the
@@ -489,7 +518,7 @@ tri_count_body(const FrameConst &fc, const uint32_t *__restrict__ count_list, Tr
     for (uint32_t i = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; i < n_count; i += waves) {
         const int fb = (int)count_list[i];
         const TriRec tb = tris[fb];
-        const double dp[3] = { attrs[fb].dp[0], attrs[fb].dp[1], attrs[fb].dp[2] };
+        const double dp[3] = { tb.dp[0], tb.dp[1], tb.dp[2] };
         const int w = tb.x1 - tb.x0;
         const long long n = (long long)w * (tb.y1 - tb.y0);
         const long long chunks = (n + WAVE - 1) / WAVE;
@@ -527,7 +556,7 @@ __device__ __forceinline__ bool sample_is_drawn(const FrameConst &fc, const TriR
 }
 
 __global__ void __launch_bounds__(256)
-k_face_status(const FrameConst fc, const TriRec *__restrict__ tris, const TriAttr *__restrict__ attrs,
+k_face_status(const FrameConst fc, const TriRec *__restrict__ tris,
               const TriClip *__restrict__ clips, const double *__restrict__ zbuf, const int32_t *__restrict__ stencil,
               uint8_t *__restrict__ status)
 {
@@ -536,7 +565,7 @@ k_face_status(const FrameConst fc, const TriRec *__restrict__ tris, const TriAtt
     const bool valid = f < fc.n_faces && status[f] == FACE_OK;
     TriRec t = {};
     double dp[3] = { 0, 0, 0 };
-    if (valid) { t = tris[f]; dp[0] = attrs[f].dp[0]; dp[1] = attrs[f].dp[1]; dp[2] = attrs[f].dp[2]; }
+    if (valid) { t = tris[f]; dp[0] = t.dp[0]; dp[1] = t.dp[1]; dp[2] = t.dp[2]; }
     const int bw = t.x1 - t.x0, bh = t.y1 - t.y0;
     const int total = valid ? bw * bh : 0;
     if (valid && total <= COUNT_SMALL_BOX) {
@@ -551,7 +580,7 @@ k_face_status(const FrameConst fc, const TriRec *__restrict__ tris, const TriAtt
         big &= big - 1;
         const int fb = __shfl(f, src);
         const TriRec tb = tris[fb];
-        const double dpb[3] = { attrs[fb].dp[0], attrs[fb].dp[1], attrs[fb].dp[2] };
+        const double dpb[3] = { tb.dp[0], tb.dp[1], tb.dp[2] };
         const int w = tb.x1 - tb.x0;
         const long long n = (long long)w * (tb.y1 - tb.y0);
         bool any = false;
@@ -603,10 +632,14 @@ __device__ __forceinline__ void quad_setup_group(bool have, int sil_f, int sil_k
     {
     SETUP_ARGS();                                                // phase: the edge's corners, extrusion
     if (have && gl < 4) {
-        const int32_t *fcx = sa.faces + (size_t)sil_f * 12;
-        const int ia = fcx[sil_k * 4], ib = fcx[((sil_k + 1) % 3) * 4];
-        const double *src = sa.verts + (size_t)((gl == 0 || gl == 3) ? ia : ib) * 4;
-        for (int j = 0; j < 4; ++j) v[j] = src[j];
+        const int corner = (gl == 0 || gl == 3) ? sil_k : (sil_k + 1) % 3;       // A, B, D, C: the edge's first / second end
+        if (fc.pos32) {
+            const float *src = static_cast<const FacePos32 *>(sa.face_pos)[sil_f].v[corner];
+            for (int j = 0; j < 4; ++j) v[j] = (double)src[j];
+        } else {
+            const double *src = static_cast<const FacePos64 *>(sa.face_pos)[sil_f].v[corner];
+            for (int j = 0; j < 4; ++j) v[j] = src[j];
+        }
         if (gl >= 2) {
             if (fc.light_type == MR_LIGHT_POINT) {
                 double d[4] = { v[0] - fc.light_pos[0], v[1] - fc.light_pos[1], v[2] - fc.light_pos[2], v[3] - 1.0 };
@@ -845,11 +878,11 @@ k_setup(const SetupKernArgs)            // read through kernargs<SetupKernArgs>(
 // latency-bound work is in flight early) and the tile lists of the large primitives.
 __global__ void __launch_bounds__(256)
 k_bin_work(const FrameConst fc, const BinArgs bins, const uint32_t *__restrict__ count_list,
-           TriRec *__restrict__ tris, const TriAttr *__restrict__ attrs, const TriClip *__restrict__ clips,
+           TriRec *__restrict__ tris, const TriClip *__restrict__ clips,
            uint8_t *__restrict__ status, Counters *__restrict__ ctr, uint32_t count_blocks)
 {
     if (blockIdx.x < count_blocks)
-        tri_count_body(fc, count_list, tris, attrs, clips, status, ctr, blockIdx.x, count_blocks);
+        tri_count_body(fc, count_list, tris, clips, status, ctr, blockIdx.x, count_blocks);
     else
         bin_work_body(fc, bins, blockIdx.x - count_blocks, gridDim.x - count_blocks);
 }

@@ -14,7 +14,8 @@ namespace mr {
 
 struct ShadeArgs {
     const TriRec *tris;
-    const TriAttr *attrs;
+    const void *face_pos;      // static per face: FacePos32[] / FacePos64[] (FrameConst::pos32)
+    const FaceAttr *face_attr; // static per face: uv, vertex normals
     const Material *materials;
     const uint8_t *sky;        // cubemap texels (6, S, S, 3) or null
     const float *gamma_lut;    // GAMMA_LUT_SIZE thresholds of the finalise step function
@@ -170,14 +171,38 @@ __device__ __forceinline__ double clip01(double v) { return v < 0.05 ? 0.05 : (v
 // Colour of one covered pixel: the reference's two shading passes collapsed: the
 // pixel shows its winner face, lit (obj/triangular.py:149-171) where the stencil count is zero,
 // ambient only (obj/triangular.py:135-147) where it is not.  `mat` may live in LDS.
-__device__ __forceinline__ void shade_pixel(const LightConst &fc, const TriRec &t, const TriAttr &at, const Material &mat,
+// what shading reads of a face: its set-up record of this frame (TriRec) and its static records
+struct ShadedFace {
+    double world[3][3];        // world xyz per corner
+    const FaceAttr *attr;
+};
+__device__ __forceinline__ void load_shaded_face(const ShadeArgs &sh, bool pos32, int face, ShadedFace &sf)
+{
+    if (pos32) {
+        const FacePos32 &p = static_cast<const FacePos32 *>(sh.face_pos)[face];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sf.world[k][j] = (double)p.v[k][j];
+    } else {
+        const FacePos64 &p = static_cast<const FacePos64 *>(sh.face_pos)[face];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sf.world[k][j] = p.v[k][j];
+    }
+    sf.attr = sh.face_attr + face;
+}
+
+__device__ __forceinline__ void shade_pixel(const LightConst &fc, const TriRec &t, const ShadedFace &sf, const Material &mat,
                                             int px, int py, bool lit, float rgb[3])
 {
+    const FaceAttr &at = *sf.attr;
     const uint8_t ff = (uint8_t)(t.flags >> 8);
     float u, v, w;
     tri_bary(t, (double)px, (double)py, (t.flags & TF_SINGLE_BOX) != 0, u, v, w);
     double p[3];
-    persp_bary(at.dp, u, v, w, false, p);
+    persp_bary(t.dp, u, v, w, false, p);
     const double tu = gemv3(p[0], p[1], p[2], (double)at.uv[0][0], (double)at.uv[1][0], (double)at.uv[2][0]);
     const double tv = gemv3(p[0], p[1], p[2], (double)at.uv[0][1], (double)at.uv[1][1], (double)at.uv[2][1]);
 
@@ -187,7 +212,7 @@ __device__ __forceinline__ void shade_pixel(const LightConst &fc, const TriRec &
     // of six wavefronts per SIMD.  Only lit pixels need the normal.
     double raw[3] = { 0, 0, 0 }, interp[3] = { 0, 0, 0 };
     bool raw_is_unit = false;
-    const double *wa = at.world[0], *wb = at.world[1], *wc = at.world[2];
+    const double *wa = sf.world[0], *wb = sf.world[1], *wc = sf.world[2];
     if (lit) {
     const bool has_n = (ff & FF_HAS_NORMALS) != 0;
     if (has_n) {

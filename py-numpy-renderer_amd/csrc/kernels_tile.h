@@ -346,7 +346,6 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         // (what the loops below read of the arguments is fetched here, once: a load through the opaque pointer is
         // not hoisted out of a loop by the compiler when it sits under a condition)
         const TriRec *__restrict__ tris = sh.tris;
-        const TriAttr *__restrict__ attrs = sh.attrs;
         const TriClip *__restrict__ clips = ta.clips;
         const uint32_t *__restrict__ small_items = ta.items[0] + (size_t)tile * ta.cap[0];
         const uint32_t *__restrict__ big_items = ta.items[1] + (size_t)tile * ta.cap[1];
@@ -393,9 +392,8 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
                     if (flags & TF_CLIP) {
                         if (in) {
                             const TriClip &c = clips[f];
-                            const TriAttr &at = attrs[f];
                             double p[3];
-                            persp_bary(at.dp, u, v, w, single, p);
+                            persp_bary(t.dp, u, v, w, single, p);
                             in = inside_clip(p, c.clip) && (same_clip || inside_clip(p, c.clipd));
                         }
                     }
@@ -725,10 +723,11 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         bool ready_u8 = false;
         if (best >= 0) {
             const TriRec t = sh.tris[best];
-            const TriAttr &at = sh.attrs[best];
+            ShadedFace sf;
+            load_shaded_face(sh, fc.pos32 != 0, best, sf);
             const Material *mp = mat_lds ? reinterpret_cast<const Material *>(s_mat) + t.material
                                          : sh.materials + t.material;
-            shade_pixel(lc, t, at, *mp, px, py, lit, rgb);
+            shade_pixel(lc, t, sf, *mp, px, py, lit, rgb);
         } else if ((fc.flags & MR_FRAME_SKYBOX) && sh.sky) {
             sky_color(fc, sh.sky, px, py, rgb);
         } else if (fc.background_u8 >> 24) {

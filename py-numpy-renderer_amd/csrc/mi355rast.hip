@@ -87,7 +87,7 @@ constexpr int EVENT_RING = 64, N_MARKS = 6;
 // Everything one in-flight frame writes.
 struct FrameSlot {
     hipStream_t stream = nullptr;                 // the stream this slot serves
-    DevBuf d_vout, d_vclip, d_tris, d_attrs, d_clips, d_status, d_count_list, d_quads, d_sil, d_counters;
+    DevBuf d_vout, d_vclip, d_tris, d_clips, d_status, d_count_list, d_quads, d_sil, d_counters;
     DevBuf d_bin_count, d_items[mr::BIN_CLASSES], d_work, d_tile_stats, d_hist, d_split;
     DevBuf d_z, d_winner, d_stencil, d_frame, d_out;
     // capacities this slot's buffers were last bound with (the scene holds the current ones)
@@ -126,7 +126,7 @@ struct FrameSlot {
     void reset_caps() { bins_zeroed_for = 0; have_frame = false; }
     void release()
     {
-        DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_attrs, &d_clips, &d_status, &d_quads, &d_sil, &d_counters,
+        DevBuf *bufs[] = { &d_vout, &d_vclip, &d_count_list, &d_tris, &d_clips, &d_status, &d_quads, &d_sil, &d_counters,
                            &d_bin_count, &d_items[0], &d_items[1], &d_items[2], &d_work, &d_tile_stats, &d_hist, &d_split,
                            &d_z, &d_winner, &d_stencil, &d_frame, &d_out };
         for (DevBuf *b : bufs) b->release();
@@ -170,6 +170,8 @@ struct mr_scene {
     DevBuf d_verts, d_uv, d_normals, d_faces, d_face_flags, d_materials, d_textures, d_edges, d_edge_inc, d_face_n;
     DevBuf d_edges32;                        // the compact edge table, when the scene allows it
     bool edge_compact = false;
+    DevBuf d_face_pos, d_face_attr;          // static per face (rast_types.h, FacePosT / FaceAttr), built by commit()
+    bool pos32 = false;                      // d_face_pos holds FacePos32 (every model's vertices are float32)
     // debug-frustum overlay: the level lists (host_overlay.h, OverlayLevels) in ONE device buffer, filled with one
     // copy from a page-locked staging buffer on the library's stream, and the kernel's scratch
     // debug-frustum overlay: the lines' points as built on the host (five targets and a depth per point, segment by
@@ -331,9 +333,21 @@ int commit(mr_scene *sc)
     if (ne > 0)
         hipLaunchKernelGGL(mr::k_edge_normals, dim3((ne + 255) / 256), dim3(256), 0, g_stream, ne, sc->d_edges.as<mr::EdgeRec>(),
                            sc->d_face_n.as<double>());
+    // the static face records: float32 corners when every model's vertices are float32
+    sc->pos32 = true;
+    for (uint8_t ff : sc->face_flags) if (!(ff & mr::FF_VERTS_F32)) { sc->pos32 = false; break; }
+    HIP_TRY(sc->d_face_pos.ensure(std::max<size_t>((size_t)nf * (sc->pos32 ? sizeof(mr::FacePos32) : sizeof(mr::FacePos64)), 16)));
+    HIP_TRY(sc->d_face_attr.ensure(std::max<size_t>((size_t)nf * sizeof(mr::FaceAttr), 16)));
+    if (nf > 0 && sc->pos32)
+        hipLaunchKernelGGL(mr::k_face_static<float>, dim3((nf + 255) / 256), dim3(256), 0, g_stream, nf, sc->d_faces.as<int32_t>(),
+                           sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_uv.as<float>(), sc->d_normals.as<float>(),
+                           sc->d_face_pos.as<mr::FacePos32>(), sc->d_face_attr.as<mr::FaceAttr>());
+    else if (nf > 0)
+        hipLaunchKernelGGL(mr::k_face_static<double>, dim3((nf + 255) / 256), dim3(256), 0, g_stream, nf, sc->d_faces.as<int32_t>(),
+                           sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_uv.as<float>(), sc->d_normals.as<float>(),
+                           sc->d_face_pos.as<mr::FacePos64>(), sc->d_face_attr.as<mr::FaceAttr>());
     // compact edge records when every model's vertices are float32 and no edge has more than two faces
-    sc->edge_compact = ne > 0 && sc->edge_inc.empty();
-    for (uint8_t ff : sc->face_flags) if (!(ff & mr::FF_VERTS_F32)) { sc->edge_compact = false; break; }
+    sc->edge_compact = ne > 0 && sc->edge_inc.empty() && sc->pos32;
     if (sc->edge_compact) {
         HIP_TRY(sc->d_edges32.ensure((size_t)ne * sizeof(mr::EdgeRec32)));
         hipLaunchKernelGGL(mr::k_edge_compact, dim3((ne + 255) / 256), dim3(256), 0, g_stream, ne, sc->d_edges.as<mr::EdgeRec>(),
@@ -424,6 +438,7 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
     for (uint8_t ff : sc->face_flags) if (ff & mr::FF_NO_DEPTH) { fc.has_no_depth = 1; break; }
     fc.same_clip = memcmp(fr->mvp, fr->debug_mvp, sizeof(fr->mvp)) == 0 ? 1 : 0;
     fc.edge_compact = sc->edge_compact ? 1 : 0;
+    fc.pos32 = sc->pos32 ? 1 : 0;
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
     fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;
@@ -553,7 +568,6 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     }
     HIP_TRY(fs->d_count_list.ensure(nF * sizeof(uint32_t)));
     HIP_TRY(fs->d_tris.ensure(nF * sizeof(TriRec)));
-    HIP_TRY(fs->d_attrs.ensure(nF * sizeof(TriAttr)));
     HIP_TRY(fs->d_clips.ensure(nF * sizeof(TriClip)));
     HIP_TRY(fs->d_status.ensure(nF));
     HIP_TRY(fs->d_quads.ensure((size_t)fs->quad_cap * sizeof(QuadRec)));
@@ -622,7 +636,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.faces = sc->d_faces.as<int32_t>(); sa.face_flags = sc->d_face_flags.as<uint8_t>();
     sa.verts = sc->d_verts.as<double>(); sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
     sa.vout = fs->d_vout.as<VertexOut>(); sa.vclip = fs->d_vclip.as<VertexClip>();
-    sa.tris = fs->d_tris.as<TriRec>(); sa.attrs = fs->d_attrs.as<TriAttr>(); sa.clips = fs->d_clips.as<TriClip>();
+    sa.face_pos = sc->d_face_pos.p;
+    sa.tris = fs->d_tris.as<TriRec>(); sa.clips = fs->d_clips.as<TriClip>();
     sa.status = fs->d_status.as<uint8_t>(); sa.count_list = fs->d_count_list.as<uint32_t>(); sa.ctr = ctr;
     sa.edges = sc->edge_compact ? reinterpret_cast<const EdgeRec *>(sc->d_edges32.p) : sc->d_edges.as<EdgeRec>(); sa.edge_inc = sc->d_edge_inc.as<uint32_t>(); sa.face_n = sc->d_face_n.as<double>();
     sa.tile_class = tile_class; sa.order = order;
@@ -651,7 +666,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         const unsigned work_blocks = 512;
         const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
         hipLaunchKernelGGL(k_bin_work, dim3(count_blocks + work_blocks), dim3(256), 0, stream, fc, ba,
-                           fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(),
+                           fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(),
                            fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), ctr, count_blocks);
     }
     if (timing) HIP_TRY(hipEventRecord(fs->ev[3], stream));
@@ -691,7 +706,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     ta.split_arrive = fs->d_split.as<uint32_t>();
     ta.split_sten = fs->d_split.as<int32_t>() + HEAVY0_MAX;
     ShadeArgs sh;
-    sh.tris = fs->d_tris.as<TriRec>(); sh.attrs = fs->d_attrs.as<TriAttr>();
+    sh.tris = fs->d_tris.as<TriRec>(); sh.face_pos = sc->d_face_pos.p; sh.face_attr = sc->d_face_attr.as<FaceAttr>();
     sh.materials = sc->d_materials.as<Material>();
     sh.sky = sc->sky_size > 0 ? sc->d_sky.as<uint8_t>() : nullptr;
     sh.gamma_lut = sc->d_gamma.as<float>();
@@ -718,7 +733,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     if (timing) HIP_TRY(hipEventRecord(fs->ev[4], stream));
     if ((fc.flags & MR_FRAME_FACE_STATUS) && fc.n_faces > 0)
         hipLaunchKernelGGL(k_face_status, dim3(blocks_for(fc.n_faces, 256)), dim3(256), 0, stream, fc,
-                           fs->d_tris.as<TriRec>(), fs->d_attrs.as<TriAttr>(), fs->d_clips.as<TriClip>(),
+                           fs->d_tris.as<TriRec>(), fs->d_clips.as<TriClip>(),
                            fs->d_z.as<double>(), fs->d_stencil.as<int32_t>(), fs->d_status.as<uint8_t>());
     if (overlay && partial) {
         const int world = fr->stripe_count > 1 ? fr->stripe_count : fr->height / (fr->row_end - fr->row_begin);
@@ -919,6 +934,7 @@ void mr_scene_destroy(mr_scene *sc)
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
                        &sc->d_textures, &sc->d_edges, &sc->d_edges32, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma,
+                       &sc->d_face_pos, &sc->d_face_attr,
                        };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();

@@ -51,6 +51,7 @@ struct FrameConst {
     int32_t out_tile_rows;       // > 0: striped output layout with this many tile rows per device (see out_row)
     int32_t n_vertices, n_faces, n_edges, n_materials;
     int32_t same_clip;           // debug_mvp == mvp bit for bit: the second clip test repeats the first
+    int32_t pos32;               // the scene's static face records hold float32 corners (FacePos32[], else FacePos64[])
     int32_t edge_compact;        // the scene's edge table is EdgeRec32[] (else EdgeRec[])
     double mvp[16], viewport[16], debug_mvp[16];
     double planes[24];
@@ -94,21 +95,34 @@ struct alignas(16) TriRec {
     int32_t face;                // global face index
     int32_t material;            // global material index of the face (first corner's group, obj/core.py:125)
     uint32_t pad;
+    double dp[3];                // 1 / clip.w per corner (perspective-correct barycentrics, obj/core.py:155-160)
+    double pad2;
 };
-static_assert(sizeof(TriRec) == 112, "TriRec layout");
+static_assert(sizeof(TriRec) == 144, "TriRec layout");
 
-// What shading needs of a face, gathered ONCE per frame by the set-up kernel (which has the
-// corners in registers anyway) instead of once per pixel through the index row: 1/w of the
-// corners (perspective-correct barycentrics, obj/core.py:155-160), world-space corners, uv and
-// vertex normals.  176 bytes = 11 x 16.
-struct alignas(16) TriAttr {
-    double dp[3];                // 1 / clip.w per corner
-    double world[3][3];          // world xyz per corner
+// STATIC per face, built when the scene is committed (k_face_static): what the index rows point at, gathered once
+// per scene instead of once per frame -- the three corners' world positions (what the set-up kernel transforms and
+// shading interpolates), the face's material and flags, and its texture coordinates and vertex normals.  A face's
+// set-up is then ONE contiguous record away (round 2: index row -> three vertex gathers, and for the faces that
+// survive the cull three uv and three normal gathers more and a 176-byte attribute record written per frame:
+// a chain of dependent trips to memory that was most of the set-up kernel's 25 us), and shading reads the same
+// records instead of a per-frame copy.  Positions are float32 when every model's vertices are (FrameConst::pos32).
+template <class T>
+struct alignas(16) FacePosT {
+    T v[3][4];                   // world-space corners (x, y, z, w)
+    int32_t material;            // global material index (first corner's group, obj/core.py:125)
+    uint32_t flags;              // FF_* of the owning model
+    uint32_t pad[2];
+};
+typedef FacePosT<float> FacePos32;
+typedef FacePosT<double> FacePos64;
+static_assert(sizeof(FacePos32) == 64 && sizeof(FacePos64) == 112, "FacePos layout");
+struct alignas(16) FaceAttr {
     float uv[3][2];
     float n[3][3];
-    float pad[3];
+    float pad;
 };
-static_assert(sizeof(TriAttr) == 176, "TriAttr layout");
+static_assert(sizeof(FaceAttr) == 64, "FaceAttr layout");
 
 // Both cameras' clip-space corners; written only for faces whose fragments need the clip test.
 struct alignas(16) TriClip {
