@@ -58,7 +58,9 @@ enum {
                                  two kernels): mr_stats.gpu_ms_* read 0 and mr_get_kernel_times skips the frame */
     MR_FRAME_OVERLAY = 256,   /* replay the statement lists of mr_scene_set_overlay (the debug-camera frustum of
                                  obj/core.py:638) on the frame after the tile kernel; implies MR_FRAME_KEEP_BUFFERS
-                                 and MR_FRAME_KEEP_FLOAT; whole frames only (no row band, no stripes) */
+                                 and MR_FRAME_KEEP_FLOAT.  On part of a frame (row band / stripes;
+                                 mr_render_device only) the overlay is not drawn: the state it needs is appended to the
+                                 rows for mr_overlay_apply, see there */
     MR_FRAME_KEEP_BUFFERS = 64 /* also write the reference's working buffers (z_buffer, stencil_buffer, winner
                                  face per pixel; obj/core.py:588-591) to device memory for mr_read_z /
                                  mr_read_stencil / mr_read_winner.  Without it they only ever exist on chip,

@@ -451,9 +451,14 @@ __device__ __forceinline__ int tri_setup_record(int f, int32_t material, uint8_t
                 cl.clipd[0][j] = ca.clipd[j]; cl.clipd[1][j] = cb.clipd[j]; cl.clipd[2][j] = cc.clipd[j];
             }
         } else {
-            clip_coords(fc, va, cl.clip[0], cl.clipd[0]);
-            clip_coords(fc, vb, cl.clip[1], cl.clipd[1]);
-            clip_coords(fc, vc, cl.clip[2], cl.clipd[2]);
+            // (rare: the corners are read again here rather than kept in 24 registers of every lane since the cull)
+            double wa[4], wb[4], wc[4];
+            int32_t m2;
+            uint8_t f2;
+            load_face_pos(sa.face_pos, fc.pos32 != 0, f, wa, wb, wc, m2, f2);
+            clip_coords(fc, wa, cl.clip[0], cl.clipd[0]);
+            clip_coords(fc, wb, cl.clip[1], cl.clipd[1]);
+            clip_coords(fc, wc, cl.clip[2], cl.clipd[2]);
         }
     }
     return count_here ? 1 : 3;
@@ -857,7 +862,7 @@ __device__ __forceinline__ void edge_block(uint32_t block)
 // First launch of the frame: workgroup 0 puts the frame's tiles in order (a serial walk of some microseconds,
 // hidden behind the others), workgroups [1, 1 + face_blocks) set faces up, the rest look at edges.
 #ifndef MR_SETUP_WAVES
-#define MR_SETUP_WAVES 4
+#define MR_SETUP_WAVES 5
 #endif
 template <bool PRE_XFORM>
 __global__ void __launch_bounds__(SETUP_BLOCK, MR_SETUP_WAVES)

@@ -1,13 +1,17 @@
-"""gpurun_out/pmc/traffic_<tag>/traffic_raw.json (tools/prof_traffic.sh) -> profiles/<round>_traffic.json:
+"""profiles/<round>_<tag>_pmc_fetch_write.txt (the table tools/prof_traffic.sh prints) -> profiles/<round>_traffic.json:
 HBM bytes per launch of the frame's kernels, per config, as bench.py's roofline.traffic reads them.
     python tools/make_traffic_json.py r02 c4 c5"""
-import json, os, sys
+import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, tags = sys.argv[1], sys.argv[2:]
 path = os.path.join(ROOT, "profiles", rnd + "_traffic.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 for tag in tags:
-    raw = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc", f"traffic_{tag}", "traffic_raw.json")))
+    raw = {}
+    for line in open(os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_fetch_write.txt")):
+        m = re.match(r"(\S+)\s+FETCH_SIZE=\s*([\d.]+) KB WRITE_SIZE=\s*([\d.]+) KB\s+us=\s*([\d.]+)", line)
+        if m:
+            raw[m.group(1)] = {"fetch": float(m.group(2)), "write": float(m.group(3)), "fetch_pass_us": float(m.group(4))}
     raw = {k.split("<")[0]: v for k, v in raw.items()}           # k_tile<false> -> k_tile
     out[tag] = {k: int((2 * v.get("fetch", 0) + v.get("write", 0)) * 1024) for k, v in raw.items() if k.startswith("k_")}
     out[tag]["_raw_kb"] = {k: {m: round(x, 2) for m, x in v.items()} for k, v in raw.items() if k.startswith("k_")}
