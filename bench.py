@@ -18,8 +18,8 @@ many as it takes for the K timed steps to last 3 s at the rate of a short calibr
 in the line says how many) -- so the timed region does not depend on --steps; successive frames use DIFFERENT per-frame
 constants (the camera swings through 8 slightly different views), and ``--frames-in-flight``
 (default 3) of them are in flight on separate HIP streams.  With N > 1 every rank renders its share
-of the screen tiles (interleaved tile rows by default, ``--partition bands`` for contiguous row
-bands) and ONE RCCL all-gather assembles the frame on every rank (fixed total work -> "strong").
+of the screen tiles (contiguous row bands of equal modelled cost by default, ``--partition stripes`` for
+interleaved tile rows, ``--partition bands`` for equal row bands) and ONE RCCL all-gather assembles the frame on every rank (fixed total work -> "strong").
 
 value = reference-equivalent fragments per frame (2 x triangle fragments + shadow-quad fragments:
 the reference rasterises every triangle in two passes) / time, summed over the views.
@@ -163,8 +163,8 @@ def main():
     ap.add_argument("--all-marks", action="store_true", help="time every stage (5 event marks per frame instead of 3)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="successive frames rendered on this many HIP streams (1 = one frame at a time)")
-    ap.add_argument("--partition", choices=("stripes", "bands"), default="stripes",
-                    help="screen-tile split for --gpus > 1: interleaved tile rows or contiguous row bands")
+    ap.add_argument("--partition", choices=("stripes", "bands", "weighted"), default="weighted",
+                    help="screen-tile split for --gpus > 1: interleaved tile rows, contiguous row bands, or bands of equal cost")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

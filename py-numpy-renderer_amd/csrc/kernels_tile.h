@@ -41,6 +41,60 @@ __device__ __forceinline__ double z_unkey(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
+// Coverage and depth of a sample as the tile kernel's pair loops evaluate them.  The reference's (N,K)@(K,) products
+// round in one of two orders (rows_dot2 / rows_dot3 in rast_math.h: a dot for one row, a gemv for more), chosen per face
+// by TF_SINGLE_BOX and TF_SINGLE_Z.  Evaluating both and selecting cost four float64 operations and four selects per
+// sample on top of the four that count, and two and two more per depth; here the ORDER is folded into the operands,
+// once per (lane, triangle):  gemv2(a0, a1, b0, b1) = chain2(a1, a0, b1, b0) and gemv3(a0, a1, a2, ...) =
+// chain3(a1, a0, a2, ...), so one chain serves both with the first two operand pairs swapped.  Same operations on the
+// same values as tri_bary / rows_dot3: bit-identical.  MAYBE_SINGLE == false: the caller knows neither flag is set.
+template <bool MAYBE_SINGLE>
+struct PairMath {
+    double a0, a1, p0, p1, q0, q1, k0, k1, k2;
+    float d00, d01, d11, inv_den;
+    bool sbox, sz;
+    __device__ __forceinline__ explicit PairMath(const TriRec &t)
+    {
+        sbox = MAYBE_SINGLE && (t.flags & TF_SINGLE_BOX) != 0;
+        sz = MAYBE_SINGLE && (t.flags & TF_SINGLE_Z) != 0;
+        a0 = sbox ? t.ax : t.ay;   a1 = sbox ? t.ay : t.ax;
+        p0 = sbox ? t.v0x : t.v0y; p1 = sbox ? t.v0y : t.v0x;
+        q0 = sbox ? t.v1x : t.v1y; q1 = sbox ? t.v1y : t.v1x;
+        k0 = sz ? t.zl0 : t.zl1;   k1 = sz ? t.zl1 : t.zl0;   k2 = t.zl2;
+        d00 = t.d00; d01 = t.d01; d11 = t.d11; inv_den = t.inv_den;
+    }
+    // tri_bary (obj/transformation.py:18-31) at the sample (x, y), given widened to double
+    __device__ __forceinline__ void bary(double x, double y, float &u, float &v, float &w) const
+    {
+        const double r0 = (sbox ? x : y) - a0, r1 = (sbox ? y : x) - a1;
+        const float d20 = (float)fma(r1, p1, r0 * p0);
+        const float d21 = (float)fma(r1, q1, r0 * q0);
+        v = (d11 * d20 - d01 * d21) * inv_den;
+        w = (d00 * d21 - d01 * d20) * inv_den;
+        u = 1.0f - v - w;
+    }
+    __device__ __forceinline__ void bary(int x, int y, float &u, float &v, float &w) const
+    {
+        bary((double)(sbox ? x : y), (double)(sbox ? y : x), true, u, v, w);
+    }
+    // bar @ zlin (obj/triangular.py:97)
+    __device__ __forceinline__ double depth(float u, float v, float w) const
+    {
+        const float m0 = sz ? u : v, m1 = sz ? v : u;
+        return fma((double)w, k2, fma((double)m1, k1, (double)m0 * k0));
+    }
+private:
+    __device__ __forceinline__ void bary(double c0, double c1, bool, float &u, float &v, float &w) const   // operands in chain order already
+    {
+        const double r0 = c0 - a0, r1 = c1 - a1;
+        const float d20 = (float)fma(r1, p1, r0 * p0);
+        const float d21 = (float)fma(r1, q1, r0 * q0);
+        v = (d11 * d20 - d01 * d21) * inv_den;
+        w = (d00 * d21 - d01 * d20) * inv_den;
+        u = 1.0f - v - w;
+    }
+};
+
 // One small (triangle, tile) pair shared by SMALL_LANES neighbouring lanes: the samples of the
 // pixel box that lie in the tile are dealt to them round-robin (a tile of a dense mesh lists
 // 50-200 such pairs of 1-24 samples each; one lane per pair left three of the four wavefronts
@@ -69,7 +123,7 @@ __device__ __forceinline__ void small_pair(const TileBounds &tb, const TriRec &t
 {
     const int x0 = max((int)t.x0, gx), x1 = min((int)t.x1, min(gx + TILE_W, tb.width));
     const int y0 = max(max((int)t.y0, gy), tb.band_y0), y1 = min(min((int)t.y1, gy + TILE_H), tb.band_y1);
-    const bool single = (t.flags & TF_SINGLE_BOX) != 0;
+    const PairMath<true> pm(t);
     // Model.depth_test == False (obj/triangular.py:117): the face's fragments are tested, never written to z.
     // The pixel then shows the LAST face in order among those that pass against the final z (see k_tile).
     const bool nodepth = ((t.flags >> 8) & FF_NO_DEPTH) != 0;
@@ -82,12 +136,11 @@ __device__ __forceinline__ void small_pair(const TileBounds &tb, const TriRec &t
     while (py < y1) {
         if (SWEEP == 0 || walked >= first) {
             float u, v, w;
-            tri_bary(t, (double)px, (double)py, single, u, v, w);
+            pm.bary(px, py, u, v, w);
             bool ok = u >= 0 && v >= 0 && w >= 0;
             if (ok && SWEEP == 0) ++frags;
             if (ok && (SWEEP == 1 || !nodepth)) {
-                const double z = rows_dot3((t.flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w,
-                                           t.zl0, t.zl1, t.zl2);
+                const double z = pm.depth(u, v, w);
                 if (z == z) {                            // a NaN depth never passes the reference's test
                     const int p = (py - gy) * TILE_W + (px - gx);
                     const unsigned long long k = z_key(z);
@@ -379,32 +432,38 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
                     const uint32_t flags = t.flags;
                     const bool nodepth = ((flags >> 8) & FF_NO_DEPTH) != 0;
                     if (late && !nodepth) continue;
-                    const int f = t.face;
-                    const bool single = (flags & TF_SINGLE_BOX) != 0;
-                    bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
-                    float u, v, w;
-                    tri_bary(t, dpx, dpy, single, u, v, w);
-                    in = in && u >= 0 && v >= 0 && w >= 0;
-                    const unsigned long long m = __ballot(in);
-                    if (!m) continue;
-                    if (!late) frags += (unsigned int)__popcll(m);
-                    if (nodepth && !late) continue;
-                    if (flags & TF_CLIP) {
-                        if (in) {
-                            const TriClip &c = clips[f];
-                            double p[3];
-                            persp_bary(t.dp, u, v, w, single, p);
-                            in = inside_clip(p, c.clip) && (same_clip || inside_clip(p, c.clipd));
+                    // the pair is the same for every lane, so are its flags: the usual face (neither of the two
+                    // summation-order flags) takes a copy of the arithmetic without their selects (see PairMath)
+                    auto pair = [&](auto maybe_single) {
+                        const PairMath<decltype(maybe_single)::value> pm(t);
+                        const int f = t.face;
+                        bool in = live && px >= t.x0 && px < t.x1 && py >= t.y0 && py < t.y1;
+                        float u, v, w;
+                        pm.bary(dpx, dpy, u, v, w);
+                        in = in && u >= 0 && v >= 0 && w >= 0;
+                        const unsigned long long m = __ballot(in);
+                        if (!m) return;
+                        if (!late) frags += (unsigned int)__popcll(m);
+                        if (nodepth && !late) return;
+                        if (flags & TF_CLIP) {
+                            if (in) {
+                                const TriClip &c = clips[f];
+                                double p[3];
+                                persp_bary(t.dp, u, v, w, (flags & TF_SINGLE_BOX) != 0, p);
+                                in = inside_clip(p, c.clip) && (same_clip || inside_clip(p, c.clipd));
+                            }
                         }
-                    }
-                    const double z = rows_dot3((flags & TF_SINGLE_Z) != 0, (double)u, (double)v, (double)w, t.zl0, t.zl1, t.zl2);
-                    if (late) {
-                        if (in && (rh ? z <= zbest : z >= zbest) && f > best) best = f;
-                    } else {
-                        // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
-                        const bool closer = rh ? (z < zbest) : (z > zbest);
-                        if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
-                    }
+                        const double z = pm.depth(u, v, w);
+                        if (late) {
+                            if (in && (rh ? z <= zbest : z >= zbest) && f > best) best = f;
+                        } else {
+                            // sequential rule "zbuf >= z writes" == smallest z, and among equal z the latest face
+                            const bool closer = rh ? (z < zbest) : (z > zbest);
+                            if (in && (closer || (z == zbest && f > best))) { zbest = z; best = f; }
+                        }
+                    };
+                    if (flags & (TF_SINGLE_BOX | TF_SINGLE_Z)) pair(std::true_type{});
+                    else pair(std::false_type{});
                 }
             }
         };

@@ -12,6 +12,10 @@ when the backend is "nccl") assembles the uint8 frame on every rank.  Two partit
 * ``"stripes"`` rank r renders the tile rows (16 screen rows) t with t mod world == r -- every rank
   gets an interleaved sample of the screen, so the load is balanced -- and one row gather
   (``unstripe``) after the all-gather puts the rows in frame order.
+* ``"weighted"`` contiguous bands again, cut on tile rows where the COST is equal instead of the row count
+  (``weighted_bands``; the cost of a tile row is what the tile kernel's own model makes of its list lengths in a
+  whole frame rendered once while priming): every rank sends as many rows as the tallest band holds (the all-gather
+  is regular) and one row gather (``unband_index``) drops the padding.
 """
 import torch
 import torch.distributed as dist
@@ -27,6 +31,64 @@ def row_band(height, rank, world):
         raise ValueError(f"{height} rows do not split evenly over {world} ranks")
     rows = height // world
     return rank * rows, (rank + 1) * rows
+
+
+def tile_row_costs(records, tiles_x):
+    """Cost of every tile row of a whole frame (bottom row first), from the tile kernel's per-tile records of that
+    frame (``DeviceRenderer.read_tile_records``: words 5-7 are the lengths of a tile's three lists) with the kernel's
+    own cost model (``tile_cost`` in csrc/kernels_tile.h: 20 + 2 small pairs + 30 big pairs + 3 shadow quads, in
+    units of ~0.1 us)."""
+    import numpy as np
+    rec = np.asarray(records, dtype=np.int64)
+    cost = 20 + 2 * rec[:, 5] + 30 * rec[:, 6] + 3 * rec[:, 7]
+    return cost.reshape(-1, int(tiles_x)).sum(axis=1)
+
+
+def weighted_bands(row_cost, height, world):
+    """Contiguous bands of output rows ``[(begin, end)] * world`` (rank 0 on top, every band at least one tile row, cut
+    on tile rows) that minimise the cost of the most expensive band; *row_cost* lists the tile rows bottom first
+    (screen y up, like the reference's buffers and the device's tile grid)."""
+    cost = [int(c) for c in row_cost][::-1]                  # top tile row first: bands are handed out in output order
+    n = len(cost)
+    if n != -(-int(height) // TILE_ROWS):
+        raise ValueError(f"{n} tile-row costs for {height} rows")
+    if not 1 <= world <= n:
+        raise ValueError(f"{world} ranks for {n} tile rows")
+
+    def cuts_for(cap):
+        """Greedy: every band takes tile rows while it stays under *cap* and leaves one for each rank behind it."""
+        cuts, at = [], 0
+        for r in range(world):
+            last = n - (world - 1 - r)                       # rows [at, last) are this band's to choose from
+            acc, end = 0, at
+            while end < last and (end == at or acc + cost[end] <= cap):
+                acc += cost[end]
+                end += 1
+            if r == world - 1 and end < n:
+                return None
+            cuts.append((at, end))
+            at = end
+        return cuts
+
+    lo, hi = max(cost), sum(cost)
+    while lo < hi:                                           # smallest cap the greedy split fits under
+        mid = (lo + hi) // 2
+        if cuts_for(mid) is None:
+            lo = mid + 1
+        else:
+            hi = mid
+    top_rows = int(height) - (n - 1) * TILE_ROWS            # the top tile row may be a partial one
+    def first_row(t):                                        # output row where tile row t (from the top) begins
+        return 0 if t == 0 else top_rows + (t - 1) * TILE_ROWS
+    return [(first_row(a), int(height) if b == n else first_row(b)) for a, b in cuts_for(lo)]
+
+
+def unband_index(bands, device=None):
+    """For every output row of the frame, its row in the all-gathered buffer of padded bands (every rank sends
+    ``max(end - begin)`` rows, its own first)."""
+    per = max(e - b for b, e in bands)
+    idx = torch.cat([torch.arange(b, e, dtype=torch.long) - b + r * per for r, (b, e) in enumerate(bands)])
+    return idx.to(device) if device is not None else idx
 
 
 def stripe_rows(height, world):
@@ -99,9 +161,9 @@ class BandRenderer:
     """
 
     def __init__(self, scene, rank=0, world=1, shadows=True, light_timing=False, frames_in_flight=1,
-                 partition="bands", timing_every=1, overlay=False):
+                 partition="bands", timing_every=1, overlay=False, streams=None):
         height, width = (int(v) for v in scene.resolution)
-        if partition not in ("bands", "stripes"):
+        if partition not in ("bands", "stripes", "weighted"):
             raise ValueError(f"unknown partition {partition!r}")
         self.rank, self.world, self.partition = rank, world, partition
         self.height, self.width = height, width
@@ -112,8 +174,16 @@ class BandRenderer:
         self.timing_every = int(timing_every)
         striped = partition == "stripes" and world > 1
         self.stripe = (rank, world) if striped else None
-        self.band = (0, height) if striped else row_band(height, rank, world)
-        rows = stripe_rows(height, world) if striped else self.band[1] - self.band[0]
+        self.bands = None
+        if partition == "weighted" and world > 1:
+            if overlay:
+                raise ValueError("the overlay of a split frame needs equal bands or stripes (mr_overlay_apply)")
+            self.bands = self._cost_bands(scene, shadows, height, width, world)
+            self.band = self.bands[rank]
+            rows = max(e - b for b, e in self.bands)         # every rank sends the tallest band's rows
+        else:
+            self.band = (0, height) if striped else row_band(height, rank, world)
+            rows = stripe_rows(height, world) if striped else self.band[1] - self.band[0]
         # The debug-frustum overlay (obj/core.py:638) of a split frame: every rank appends the state (z, float colour)
         # of the touched pixels it owns to its rows, the ONE all-gather carries rows and state, and every rank replays
         # the overlay on the assembled frame (include/mi355rast.h, mr_overlay_apply): the lines test z at pixels other
@@ -130,19 +200,23 @@ class BandRenderer:
         self.lanes = []
         self.count = 0
         self.descs = []
-        for _ in range(max(1, int(frames_in_flight))):
-            stream = torch.cuda.Stream()
+        for lane in range(max(1, int(frames_in_flight))):
+            # (a scene keeps work buffers per stream it has been rendered on, 32 at most: a caller that builds many
+            # renderers for one scene hands them the same streams)
+            stream = streams[lane] if streams else torch.cuda.Stream()
             frame = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
             if self.state_bytes:            # rows + state travel as one flat buffer; the rows are copied out after the gather
                 part = torch.zeros(self.part_bytes, dtype=torch.uint8, device="cuda")
                 gathered = torch.empty(self.part_bytes * world, dtype=torch.uint8, device="cuda")
             else:
                 part = frame if world == 1 else torch.empty((rows, width, 3), dtype=torch.uint8, device="cuda")
-                gathered = torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda") if striped else frame
+                gathered = (torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda")
+                            if striped or self.bands else frame)
             self.lanes.append((stream, frame, part, gathered))
         self.rows_all = (torch.empty((rows * world, width, 3), dtype=torch.uint8, device="cuda")
                          if self.state_bytes and striped else None)
-        self.index = unstripe_index(height, world, "cuda") if striped else None
+        self.index = (unstripe_index(height, world, "cuda") if striped else
+                      unband_index(self.bands, "cuda") if self.bands else None)
         # the collective's operands, flattened once (step() is the host's per-frame cost: keep it to the calls)
         self._flat = [(g.view(-1), p.view(-1)) for _, _, p, g in self.lanes]
         self._direct = world > 1 and dist.is_initialized() and dist.get_backend() != "gloo"
@@ -150,6 +224,18 @@ class BandRenderer:
         self.descs, self.descs_untimed = [], []
         self.prime()
         self.frame = self.lanes[0][1]
+
+    def _cost_bands(self, scene, shadows, height, width, world):
+        """One whole frame on this device (every rank renders the same one and reads the same list lengths, so all
+        arrive at the same cuts without talking), then the bands of equal cost."""
+        tmp = torch.empty((height, width, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(6):
+            self.backend.render_device(scene, tmp.data_ptr(), torch.cuda.current_stream().cuda_stream, shadows=shadows)
+            torch.cuda.current_stream().synchronize()
+            if not self.backend.overflowed():
+                break
+        costs = tile_row_costs(self.backend.read_tile_records(), -(-width // 16))
+        return weighted_bands(costs, height, world)
 
     def prime(self):
         """One frame per lane through the full host path (scene sync, frame packing); repeated while

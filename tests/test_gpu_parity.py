@@ -184,6 +184,38 @@ def test_tile_row_stripes_tile_the_frame(api, name, world):
     scene.close()
 
 
+@pytest.mark.parametrize("name,world", [("diablo_floor_small", 3), ("c4_torus200k_1080p", 4), ("c4_torus200k_1080p", 8),
+                                        ("c3_diablo_floor_1080p", 2)])
+def test_cost_weighted_bands_tile_the_frame(api, name, world):
+    """Screen-tile split, bands of equal COST (partition="weighted"): the cuts come from the tile records of a whole
+    frame, every rank's band is rendered into a buffer as tall as the tallest band, and the row gather after the
+    all-gather gives the whole frame; the cuts even the modelled cost out better than equal bands do."""
+    import torch
+    from py_numpy_renderer_amd.multigpu import row_band, tile_row_costs, unband_index, weighted_bands
+    scene = scenes.build(api, name)
+    backend = scene._backend()
+    full = scene.render()
+    h, w = full.shape[:2]
+    costs = tile_row_costs(backend.read_tile_records(), -(-w // 16))
+    assert len(costs) == -(-h // 16)
+    bands = weighted_bands(costs, h, world)
+    per = max(e - b for b, e in bands)
+    parts = []
+    for b, e in bands:
+        part = np.zeros((per, w, 3), np.uint8)
+        part[:e - b] = backend.render(scene, counters=False, row_band=(b, e))
+        parts.append(part)
+    frame = torch.from_numpy(np.concatenate(parts, axis=0)).index_select(0, unband_index(bands)).numpy()
+    assert np.array_equal(frame, full)
+    top = costs[::-1]
+    top_rows = h - (len(costs) - 1) * 16
+    tile_of = lambda row: 0 if row == 0 else (row - top_rows) // 16 + 1
+    worst = lambda bb: max(int(top[tile_of(b):(len(top) if e == h else tile_of(e))].sum()) for b, e in bb)
+    if h % world == 0 and (h // world) % 16 == 0:
+        assert worst(bands) <= worst([row_band(h, r, world) for r in range(world)])
+    scene.close()
+
+
 @pytest.mark.parametrize("name,world,rank", [("c4_torus200k_1080p", 8, 3), ("c3_diablo_floor_1080p", 8, 2)])
 def test_split_heavy_tiles_render_the_same_rows(api, name, world, rank):
     """A device that owns few tiles (a rank of a multi-GPU split) shares the shadow quads of its heaviest tiles

@@ -16,7 +16,8 @@ import torch.multiprocessing as mp
 
 import scenes
 from conftest import load_golden
-from py_numpy_renderer_amd.multigpu import (all_gather_frame, row_band, stripe_rows, unstripe, unstripe_index)
+from py_numpy_renderer_amd.multigpu import (all_gather_frame, row_band, stripe_rows, tile_row_costs, unband_index, unstripe,
+                                             unstripe_index, weighted_bands)
 
 
 def test_row_band_partition():
@@ -27,6 +28,38 @@ def test_row_band_partition():
         row_band(1080, 0, 7)
     with pytest.raises(ValueError):
         row_band(10, 3, 2)
+
+
+def test_weighted_bands_cut_on_tile_rows_and_balance_the_cost():
+    rng = np.random.default_rng(7)
+    for height in (1080, 2160, 270, 64, 17):
+        n = -(-height // 16)
+        top_rows = height - (n - 1) * 16
+        for world in (1, 2, 3, 4, 8):
+            if world > n:
+                with pytest.raises(ValueError):
+                    weighted_bands(np.ones(n), height, world)
+                continue
+            cost = rng.integers(1, 1000, n)
+            bands = weighted_bands(cost, height, world)
+            assert bands[0][0] == 0 and bands[-1][1] == height
+            assert all(b[1] == c[0] for b, c in zip(bands, bands[1:])) and all(e > b for b, e in bands)
+            assert all(b == 0 or (b - top_rows) % 16 == 0 for b, _ in bands)          # cuts sit on tile rows
+            tile_of = lambda row: 0 if row == 0 else (row - top_rows) // 16 + 1       # from the top
+            top = cost[::-1]
+            worst = max(int(top[tile_of(b):(n if e == height else tile_of(e))].sum()) for b, e in bands)
+            if world == 2:                                                            # against brute force
+                assert worst == min(max(top[:k].sum(), top[k:].sum()) for k in range(1, n))
+            assert worst <= max(int(top.sum()) // world + int(top.max()), int(top.max()))
+            idx = unband_index(bands)
+            assert len(idx) == height and len(set(idx.tolist())) == height
+    # a frame whose bottom tile rows hold all the work: the top band takes everything else
+    assert weighted_bands([100] * 10 + [1] * 58, 1080, 4) == [(0, 952), (952, 1000), (1000, 1048), (1048, 1080)]
+    with pytest.raises(ValueError):
+        weighted_bands(np.ones(5), 1080, 2)
+    rec = np.zeros((6, 12), np.uint32)
+    rec[:, 5], rec[:, 6], rec[:, 7] = [1, 0, 0, 0, 2, 0], [0, 1, 0, 0, 0, 0], [0, 0, 5, 0, 0, 0]
+    assert tile_row_costs(rec, 3).tolist() == [20 + 2 + 20 + 30 + 20 + 15, 20 + 20 + 4 + 20]
 
 
 def stripe_pack(frame, rank, world):
@@ -71,28 +104,40 @@ def _worker(rank, world, port, name, partition, result_dir):
         scene = scenes.build(scenes.product_api(), name)
         height = int(scene.resolution[0])
         packed = pack_scene(scene, shadows=True)
-        if partition == "bands":
-            band = row_band(height, rank, world)
+        bands = None
+        if partition == "weighted":
+            # bands of equal cost: here the cost of a tile row is made up (the device takes it from its tile records),
+            # all that matters is that every rank arrives at the same unequal cuts
+            bands = weighted_bands(np.arange(-(-height // 16)) ** 2 + 1, height, world)
+            assert len({e - b for b, e in bands}) > 1, "the test wants unequal bands"
+        if partition in ("bands", "weighted"):
+            band = bands[rank] if bands else row_band(height, rank, world)
             mine = oracle.render_packed(packed, own_rows=band, want_status=False, want_silhouette=False)
             part = np.ascontiguousarray(mine.out[band[0]:band[1]])
+            if bands:                                # every rank sends the tallest band's rows, its own first
+                pad = np.zeros((max(e - b for b, e in bands),) + part.shape[1:], part.dtype)
+                pad[:part.shape[0]] = part
+                part = pad
         else:
             mine = oracle.render_packed(packed, own_stripe=(rank, world), want_status=False, want_silhouette=False)
             part = stripe_pack(mine.out, rank, world)
         # rows the rank does not own were not rendered: they still hold the background
         other = np.ones(height, bool)
-        if partition == "bands":
+        if partition in ("bands", "weighted"):
             other[band[0]:band[1]] = False
         else:
             other[[height - 1 - py for py in range(height) if (py // 16) % world == rank]] = False
         assert (mine.winner[::-1][other] == -1).all(), "a rank rendered rows it does not own"
         gathered = all_gather_frame(torch.from_numpy(part))
-        frame = gathered if partition == "bands" else unstripe(gathered, height, world)
+        frame = (gathered if partition == "bands" else
+                 gathered.index_select(0, unband_index(bands)) if bands else unstripe(gathered, height, world))
         np.save(os.path.join(result_dir, f"rank{rank}.npy"), frame.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("partition,world", [("bands", 2), ("bands", 3), ("stripes", 2), ("stripes", 3)])
+@pytest.mark.parametrize("partition,world", [("bands", 2), ("bands", 3), ("stripes", 2), ("stripes", 3), ("weighted", 2),
+                                             ("weighted", 3)])
 def test_ranks_render_their_tiles_and_gather_the_golden_frame(api, oracle_mod, tmp_path, partition, world):
     name = "diablo_floor_small"                      # 270 rows: splits evenly in 2 and 3; 17 tile rows
     g, _ = load_golden(name)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ranks,config,partition", [(2, "c3", "stripes"), (3, "c2", "bands")])
+@pytest.mark.parametrize("ranks,config,partition", [(2, "c3", "stripes"), (3, "c2", "bands"), (3, "c3", "weighted")])
 def test_bench_multi_rank_path_on_one_gpu(ranks, config, partition):
     env = dict(os.environ, MR_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",

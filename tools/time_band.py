@@ -18,8 +18,12 @@ h = sc.resolution[0]
 IN_FLIGHT = int(os.environ.get("FRAMES_IN_FLIGHT", "1"))       # 1: one stream, frames back to back; 3: bench.py's default
 
 
+STREAMS = [torch.cuda.Stream() for _ in range(IN_FLIGHT)]
+
+
 def per_frame(world, rank, partition, frames=300):
-    br = BandRenderer(sc, rank, world, shadows=shadows, frames_in_flight=IN_FLIGHT, partition=partition, timing_every=0)
+    br = BandRenderer(sc, rank, world, shadows=shadows, frames_in_flight=IN_FLIGHT, partition=partition, timing_every=0,
+                      streams=STREAMS)
     br.world = 1                                    # this device only: no collective
     br.index = None
     for _ in range(30):
@@ -34,7 +38,7 @@ def per_frame(world, rank, partition, frames=300):
 
 print(name, "whole frame us", round(per_frame(1, 0, "bands"), 1), flush=True)
 for n in (int(a) for a in sys.argv[2:]):
-    for partition in ("bands", "stripes"):
+    for partition in ("bands", "stripes", "weighted"):
         if partition == "bands" and h % n:
             continue
         t = [per_frame(n, r, partition) for r in range(n)]
