@@ -203,10 +203,13 @@ static_assert(sizeof(Material) % 8 == 0 && MAT_LDS * sizeof(Material) / 8 <= TIL
 // compiler hoists the frame constants' register copies out of it; per-class lists appended to with atomics
 // held every workgroup for the 2 us of a device-scope atomic's round trip: 82 -> 119 us.)
 // cost thresholds of classes 1..7 (tile_cost units, ~0.1 us); the rest is class 8
+#ifndef MR_CLASS_SCALE
+#define MR_CLASS_SCALE 100            // per cent: tools/ab.sh "-DMR_CLASS_SCALE=70" ... moves all seven limits at once
+#endif
 __device__ __forceinline__ int tile_class(uint32_t cost)
 {
-    return cost >= 500u ? 1 : cost >= 350u ? 2 : cost >= 250u ? 3 : cost >= 170u ? 4 : cost >= 110u ? 5 : cost >= 70u ? 6
-         : cost >= 40u ? 7 : 8;
+    const uint32_t c = cost * 100u / (uint32_t)MR_CLASS_SCALE;
+    return c >= 500u ? 1 : c >= 350u ? 2 : c >= 250u ? 3 : c >= 170u ? 4 : c >= 110u ? 5 : c >= 70u ? 6 : c >= 40u ? 7 : 8;
 }
 static_assert(ORDER_CLASSES == 8, "tile_class");
 // On a device that owns few tiles (a rank of a multi-GPU split: all its tiles are resident at once and
