@@ -166,11 +166,12 @@ constexpr uint32_t WORK_NONE = 0xffffffffu;     // a reserved work item nobody n
 
 // first half: the wavefront's reservation (one atomic; its result is not looked at here, so other requests can
 // be in flight beside it).  Every lane must call it; returns false when no lane has anything.
-struct WorkSlot { uint32_t base_raw, offset; };
+struct WorkSlot { uint32_t base_raw, offset, shard; };
 __device__ __forceinline__ bool reserve_work_items(const BinArgs &a, uint32_t chunks, WorkSlot &w)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     w.base_raw = 0; w.offset = 0;
+    w.shard = (blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE) & (WORK_SHARDS - 1);     // neighbouring wavefronts, different cursors
     if (!__ballot(chunks != 0)) return false;
     uint32_t incl = chunks;
 #pragma unroll
@@ -179,16 +180,17 @@ __device__ __forceinline__ bool reserve_work_items(const BinArgs &a, uint32_t ch
         if (lane >= off) incl += y;
     }
     const uint32_t wave_total = __shfl(incl, WAVE - 1);
-    if (lane == 0) w.base_raw = atomicAdd(&a.ctr->n_work, wave_total);
+    if (lane == 0) w.base_raw = atomicAdd(&a.ctr->work[w.shard].n, wave_total);
     w.offset = incl - chunks;
     return true;
 }
-// second half: every lane writes its own items
+// second half: every lane writes its own items (into its cursor's stretch of the list: work_cap / WORK_SHARDS items)
 __device__ __forceinline__ void fill_work_items(const BinArgs &a, const WorkSlot &w, uint32_t prim, uint32_t chunks)
 {
+    const uint32_t per = a.work_cap / WORK_SHARDS;
     const uint32_t base = __shfl(w.base_raw, 0) + w.offset;
     for (uint32_t c = 0; c < chunks; ++c) {
-        if (base + c < a.work_cap) a.work[base + c] = make_uint2(prim, c);
+        if (base + c < per) a.work[w.shard * per + base + c] = make_uint2(prim, c);
         else atomicOr(&a.ctr->overflow, 8u);
     }
 }
@@ -242,11 +244,23 @@ __device__ __forceinline__ uint32_t quad_chunks(const FrameConst &fc, int x0, in
 // The work items: one wavefront per item, one tile per lane.
 __device__ __forceinline__ void bin_work_body(const FrameConst &fc, const BinArgs &a, uint32_t block, uint32_t n_blocks)
 {
-    const uint32_t n_work = min(a.ctr->n_work, a.work_cap);
     const int lane = threadIdx.x & (WAVE - 1);
+    // the list is WORK_SHARDS stretches (reserve_work_items): lane s knows how many items stretch s holds and where
+    // they start in the walk over all of them
+    const uint32_t per = a.work_cap / WORK_SHARDS;
+    const uint32_t mine = lane < WORK_SHARDS ? min(a.ctr->work[lane].n, per) : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < WORK_SHARDS; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    const uint32_t n_work = __shfl(incl, WORK_SHARDS - 1);
     const uint32_t waves = n_blocks * (blockDim.x / WAVE);
     for (uint32_t w = block * (blockDim.x / WAVE) + threadIdx.x / WAVE; w < n_work; w += waves) {
-        const uint2 item = a.work[w];
+        const int s = __ffsll((long long)__ballot(lane < WORK_SHARDS && incl > w)) - 1;      // the stretch item w lies in
+        const uint32_t first = __shfl(incl - mine, s);
+        const uint2 item = a.work[(uint32_t)s * per + (w - first)];
         if (item.x == WORK_NONE) continue;
         const bool is_quad = (item.x & WORK_QUAD) != 0;
         const uint32_t id = item.x & ~WORK_QUAD;

@@ -749,19 +749,24 @@ __device__ __forceinline__ void quad_setup_group(bool have, int sil_f, int sil_k
     double xs[2] = { lo_x, hi_x }, ys[2] = { lo_y, hi_y };
     int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
     const bool boxed = alive && bound_box(xs, ys, 2, fc.width, fc.height, bx0, bx1, by0, by1);
-    // the quad's record slot and its work items of 64 tiles (kernels_bin.h; all lanes take part): two returning
-    // atomics, ~2 us each, both requested before either answer is used
-    uint32_t slot = 0;
-    if (boxed && gl == 0) slot = atomicAdd(&sa.ctr->n_quads_drawn, 1u);
+    // The quad's record sits at its silhouette index (the wavefront's ONE atomic on n_quads, requested before the set-up
+    // began, came back long ago): a slot of its own from a second counter cost a returning atomic per quad, and ~1 200
+    // of those on one cache line within a few microseconds are served one after the other, 12 ns each
+    // (tools/micro/atomic_same_addr.hip) -- up to 14 us at the end of every chain.  Its work items of 64 tiles
+    // (kernels_bin.h; all lanes take part) take one more returning atomic per wavefront, on one of WORK_SHARDS cursors.
+    const uint32_t s_idx = (uint32_t)__shfl((int)s_base_raw, 0) + s_rank;
+    const uint32_t slot = s_idx;
     const uint32_t chunks = (boxed && gl == 0) ? quad_chunks(fc, bx0, bx1, by0, by1) : 0u;
     WorkSlot ws;
     const bool any_work = reserve_work_items(bins, chunks, ws);
-    slot = (uint32_t)__shfl((int)slot, g0);
+    {
+        const unsigned long long drawn = __ballot(boxed && gl == 0);           // (a statistic: nobody waits for it)
+        if (lane == 0 && drawn) atomicAdd(&sa.ctr->n_quads_drawn, (uint32_t)__popcll(drawn));
+    }
     if (any_work) fill_work_items(bins, ws, slot < sa.quad_cap ? (WORK_QUAD | slot) : WORK_NONE, chunks);
     if (!boxed) return;
     if (slot >= sa.quad_cap) { if (gl == 0) atomicOr(&sa.ctr->overflow, 16u); return; }
 
-    const uint32_t s_idx = (uint32_t)__shfl((int)s_base_raw, 0) + s_rank;
     QuadRec &q = sa.quads[slot];
     if (gl < MAX_POLY) {
         QuadEdge e;

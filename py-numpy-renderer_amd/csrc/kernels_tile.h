@@ -293,21 +293,27 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         rh = fc.system == 1;
         counters = (fc.flags & MR_FRAME_COUNTERS) != 0;
 
-        if (blockIdx.x == 0 && tid == 0) {
+        if (blockIdx.x == 0) {
             // The next frame's counter block is the previous frame's (double-buffered by parity; that frame is
             // complete: same stream).  Its overflow verdicts move to the slot's sticky record before the block is
             // cleared; nobody touches either before this kernel ends.
-            const Counters &old = *ta.next_ctr;
-            if (old.overflow | old.n_quads | old.n_work) {
-                Sticky &st = *ta.sticky;
-                st.overflow |= old.overflow;
+            if (tid == 0) {
+                const Counters &old = *ta.next_ctr;
+                uint32_t longest = 0;                     // the fullest stretch of the work list decides what the list needs
+                for (int s = 0; s < WORK_SHARDS; ++s) longest = max(longest, old.work[s].n);
+                if (old.overflow | old.n_quads | longest) {
+                    Sticky &st = *ta.sticky;
+                    st.overflow |= old.overflow;
 #pragma unroll
-                for (int c = 0; c < BIN_CLASSES; ++c) st.max_list[c] = max(st.max_list[c], old.max_list[c]);
-                st.n_work = max(st.n_work, old.n_work);
-                st.n_quads = max(st.n_quads, old.n_quads);
-                st.n_quads_drawn = max(st.n_quads_drawn, old.n_quads_drawn);
+                    for (int c = 0; c < BIN_CLASSES; ++c) st.max_list[c] = max(st.max_list[c], old.max_list[c]);
+                    st.n_work = max(st.n_work, longest * (uint32_t)WORK_SHARDS);
+                    st.n_quads = max(st.n_quads, old.n_quads);
+                    st.n_quads_drawn = max(st.n_quads_drawn, old.n_quads_drawn);
+                }
             }
-            *ta.next_ctr = Counters{};
+            __syncthreads();
+            uint32_t *words = reinterpret_cast<uint32_t *>(ta.next_ctr);
+            for (int i = tid; i < (int)(sizeof(Counters) / 4); i += TILE_PX) words[i] = 0u;
         }
 
         // heaviest tiles first: entry blockIdx.x of the order k_setup left (see tile_class)

@@ -813,7 +813,9 @@ int collect(mr_scene *sc, FrameSlot *fs, bool with_copy)
     // the verdicts of the last frame and of every frame of this slot since the host last looked (Sticky)
     mr::Sticky &st = *fs->h_sticky;
     const uint32_t overflow = c.overflow | st.overflow;
-    const uint32_t n_work = std::max(c.n_work, st.n_work), n_quads = std::max(c.n_quads, st.n_quads);
+    uint32_t longest_stretch = 0;             // the work list is WORK_SHARDS stretches: the fullest one decides what it needs
+    for (const auto &w : c.work) longest_stretch = std::max(longest_stretch, w.n);
+    const uint32_t n_work = std::max(longest_stretch * (uint32_t)mr::WORK_SHARDS, st.n_work), n_quads = std::max(c.n_quads, st.n_quads);
     const uint32_t n_quads_drawn = std::max(c.n_quads_drawn, st.n_quads_drawn);
     bool grown = false;
     if (overflow) {
@@ -928,7 +930,7 @@ int mr_scene_set_list_capacities(mr_scene *sc, uint32_t small_pairs, uint32_t bi
     if (small_pairs) sc->bin_cap[0] = small_pairs;
     if (big_pairs) sc->bin_cap[1] = big_pairs;
     if (quads) sc->bin_cap[2] = quads;
-    if (work) sc->work_cap = work;
+    if (work) sc->work_cap = std::max(work, (uint32_t)mr::WORK_SHARDS);
     return MR_OK;
 }
 

@@ -180,6 +180,7 @@ struct Material {
 // Device-side counters of one frame; copied back when somebody asks.  The words that many
 // wavefronts add to during a frame sit on cache lines of their own: atomics to one line retire
 // at ~0.3 per ns on MI355X whatever the address in it (tools/micro/atomic_bench.hip).
+constexpr int WORK_SHARDS = 16;
 struct alignas(128) Counters {
     unsigned long long frag_tri, frag_quad, covered_px, lit_px, stencil_updates;
     unsigned int n_valid_tris, tri_bin_total, bin_total;
@@ -189,9 +190,13 @@ struct alignas(128) Counters {
     unsigned int n_quads;        unsigned int pad1[31];     // silhouette edges
     unsigned int n_quads_drawn;  unsigned int pad2[31];     // quads that got a record
     unsigned int n_count;        unsigned int pad3[31];     // faces whose survivor count is left to k_bin_work
-    unsigned int n_work;         unsigned int pad4[31];     // (large primitive, 64-tile chunk) work items
+    // (large primitive, 64-tile chunk) work items: WORK_SHARDS cursors, one cache line each, every one with its own
+    // stretch of the work list.  Returning atomics on ONE line are served one after the other, ~12 ns each on MI355X
+    // (tools/micro/atomic_same_addr.hip): the thousand wavefronts that reserve items within a few microseconds of each
+    // other queued for 12 us behind a single cursor.
+    struct alignas(128) WorkCursor { unsigned int n; unsigned int pad[31]; } work[WORK_SHARDS];
 };
-static_assert(sizeof(Counters) == 128 * 5, "Counters layout");
+static_assert(sizeof(Counters) == 128 * (4 + WORK_SHARDS), "Counters layout");
 
 // What must outlive a frame's counters.  The counters are double-buffered by frame parity and a frame's tile
 // kernel clears the block of the frame after it, i.e. the block of the frame BEFORE it: the overflow verdicts of a

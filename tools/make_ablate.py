@@ -18,6 +18,9 @@ edits = [
      "        if (MR_ABLATE == 2) n_quad = 0;\n        if (MR_ABLATE == 3) n_small = 0;\n        if (MR_ABLATE == 4) n_big = 0;\n"),
     ("            round = 0;\n            for (uint32_t i = my_pair; i < n_small; i += per_round, ++round) {\n                int first = 0;",
      "            round = 0;\n            for (uint32_t i = my_pair; i < (MR_ABLATE == 5 ? 0u : n_small); i += per_round, ++round) {\n                int first = 0;"),
+    # 6: the winners' sweep answers from the cache only (what would a cache that always answers be worth?)
+    ("                    if (!nodepth && walked <= SWEEP_CACHE_K) continue;     // the cache answered for every sample of this lane",
+     "                    if (MR_ABLATE == 6 || (!nodepth && walked <= SWEEP_CACHE_K)) continue;"),
     # 1: no shading arithmetic (the records are still fetched)
     ("            shade_pixel(lc, t, sf, *mp, px, py, lit, rgb);",
      "            if (MR_ABLATE == 1) rgb[0] = (float)sf.world[0][0] + (float)mp->ns + t.d00 + (float)lc.light_pos[0]; else shade_pixel(lc, t, sf, *mp, px, py, lit, rgb);"),
