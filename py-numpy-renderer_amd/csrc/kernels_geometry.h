@@ -312,7 +312,7 @@ struct SetupArgs {
 // k_setup's arguments in one block, read phase by phase through kernargs<>() (rast_math.h): the three 4x4 matrices,
 // the six planes and two dozen pointers do not fit the scalar registers at once, and read as plain arguments they
 // were all fetched at the top and parked in vector-register lanes.
-struct SetupKernArgs { FrameConst fc; SetupArgs sa; BinArgs bins; uint32_t face_blocks; };
+struct SetupKernArgs { FrameConst fc; SetupArgs sa; BinArgs bins; uint32_t face_blocks; uint32_t edge_spread; };
 #define SETUP_ARGS() const SetupKernArgs &ka_ = kernargs<SetupKernArgs>(); const FrameConst &fc = ka_.fc; \
                      const SetupArgs &sa = ka_.sa; const BinArgs &bins = ka_.bins; (void)fc; (void)sa; (void)bins
 
@@ -802,10 +802,16 @@ __device__ __forceinline__ void edge_block(uint32_t block)
     SETUP_ARGS();
     __shared__ double s_poly[SETUP_BLOCK / WAVE][WAVE / QS_LANES][MAX_POLY + 4][4];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    const int e = (int)(block * blockDim.x + threadIdx.x);
+    // A wavefront sets its silhouette edges up four at a time, one round after the other, 10-15 us each.  A mesh of a few
+    // thousand edges of which one in ten is on the silhouette (c3: 7 500 edges, 120 wavefronts with five or six each)
+    // then spends two or three rounds where a large mesh (one silhouette edge in 250) spends one: for small scenes only
+    // every (1 << edge_spread)-th lane takes an edge, and there are that many more wavefronts.
+    const uint32_t spread = ka_.edge_spread;
+    const uint32_t slot_in_grid = block * blockDim.x + threadIdx.x;
+    const int e = (int)(slot_in_grid >> spread);
     bool sil = false;
     uint32_t last = 0;
-    if (e < fc.n_edges) {
+    if ((slot_in_grid & ((1u << spread) - 1u)) == 0 && e < fc.n_edges) {
         EdgeRec r;
         if (fc.edge_compact) {
             const EdgeRec32 c = reinterpret_cast<const EdgeRec32 *>(sa.edges)[e];

@@ -225,7 +225,10 @@ static_assert(ORDER_CLASSES == 8, "tile_class");
 // heaviest tiles started first a whole frame's launch lasts exactly as long as its single heaviest tile (c4:
 // 63.7 of 64.4 us, 46 of them its 111 shadow quads), so a lone whole frame now shares out its few heaviest tiles
 // too -- a dozen on c4, chosen by a higher threshold (TileArgs::split_cost / split_quads) -- and nothing else.
-constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = 128;
+#ifndef MR_HEAVY0_MAX
+#define MR_HEAVY0_MAX 128
+#endif
+constexpr int HEAVY_SPLIT = 4, HEAVY0_MAX = MR_HEAVY0_MAX;
 #ifndef MR_TILE_WAVES
 #define MR_TILE_WAVES 5
 #endif
@@ -255,7 +258,8 @@ struct TileArgs {
     uint32_t *split_arrive;       // [HEAVY0_MAX] parts that have left theirs (zero between frames)
     const uint32_t *order;        // ORDER_HEAD words, then the tiles in the order to render them (k_bin_work); null: row-major
     uint8_t *tile_class;          // [n_tiles] what this frame leaves for the next: 1 + the tile's cost class
-    uint32_t split_cost, split_quads;   // k_tile<true>: a tile this costly, with this many shadow quads, is shared out next frame
+    uint32_t split_cost, split_quads;   // k_tile<true>: a tile this costly, with this many shadow quads, is shared out next frame ...
+    uint32_t split_max;                 // ... if no more than this many are (<= HEAVY0_MAX)
 };
 
 struct TileKernArgs { FrameConst fc; TileArgs ta; ShadeArgs sh; };
@@ -319,7 +323,11 @@ k_tile(const TileKernArgs)            // read through kernargs<TileKernArgs>(), 
         // heaviest tiles first: entry blockIdx.x of the order k_setup left (see tile_class)
         uint32_t idx = blockIdx.x;
         if (SPLIT) {
-            const uint32_t n0 = ta.order ? min(ta.order[0], (uint32_t)HEAVY0_MAX) : 0u;   // the class whose quads are shared out
+            // the class whose quads are shared out -- when it is a handful of tiles, i.e. when the launch would end on them
+            // alone; a frame with hundreds of them keeps the device full to the end, and rasterising each four times
+            // only adds to that (c3: 209 qualify, k_tile 76 -> 84 us with the split; c5: 143, 253 -> 270; c4: some 40, 66 -> 63)
+            const uint32_t n_heavy = ta.order ? ta.order[0] : 0u;
+            const uint32_t n0 = n_heavy <= ta.split_max ? n_heavy : 0u;
             if (idx < (uint32_t)SPLIT_FRONT) {
                 entry = (int)idx / HEAVY_SPLIT;
                 part = (int)idx % HEAVY_SPLIT;

@@ -654,9 +654,14 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     if (all_marks) HIP_TRY(hipEventRecord(fs->ev[1], stream));
     {
         const unsigned face_blocks = fc.n_faces > 0 ? blocks_for(fc.n_faces, SETUP_BLOCK) : 0u;
-        const unsigned edge_blocks = (shadows && fc.n_edges > 0) ? blocks_for(fc.n_edges, SETUP_BLOCK) : 0u;
+        // small meshes: one edge per 2 / 4 lanes, so that a wavefront rarely finds more silhouette edges than one round
+        // of its quad set-up takes (kernels_geometry.h, edge_block)
+        static const int spread_env = getenv("MR_EDGE_SPREAD") ? atoi(getenv("MR_EDGE_SPREAD")) : -1;
+        const unsigned spread = spread_env >= 0 ? (unsigned)std::min(spread_env, 4)
+                              : fc.n_edges <= (1 << 15) ? 2u : fc.n_edges <= (1 << 17) ? 1u : 0u;
+        const unsigned edge_blocks = (shadows && fc.n_edges > 0) ? blocks_for((long long)fc.n_edges << spread, SETUP_BLOCK) : 0u;
         SetupKernArgs ska;
-        ska.fc = fc; ska.sa = sa; ska.bins = ba; ska.face_blocks = face_blocks;
+        ska.fc = fc; ska.sa = sa; ska.bins = ba; ska.face_blocks = face_blocks; ska.edge_spread = spread;
         if (vertex_mfma)
             hipLaunchKernelGGL(k_setup<true>, dim3(1 + face_blocks + edge_blocks), dim3(SETUP_BLOCK), 0, stream, ska);
         else
@@ -727,6 +732,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     static const unsigned split_quads_big = [] { const char *e = getenv("MR_SPLIT_QUADS"); return e ? (unsigned)atoi(e) : 48u; }();
     tka.ta.split_cost = small_grid ? 350u : split_cost_big;
     tka.ta.split_quads = small_grid ? 32u : split_quads_big;
+    static const unsigned split_max_big = [] { const char *e = getenv("MR_SPLIT_MAX"); return e ? (unsigned)atoi(e) : 64u; }();
+    tka.ta.split_max = std::min<unsigned>(small_grid ? (unsigned)HEAVY0_MAX : split_max_big, (unsigned)HEAVY0_MAX);
     const bool split = split_mode < 0 ? (small_grid || ordered) : split_mode != 0;
     if (n_tiles > 0 && split)
         hipLaunchKernelGGL(k_tile<true>, dim3((unsigned)(n_tiles + SPLIT_FRONT)), dim3(TILE_PX), 0, stream, tka);

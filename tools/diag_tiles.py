@@ -46,3 +46,7 @@ print("quad tiles", q.sum(), "mean dur", dur[q].mean() if q.any() else 0)
 A = np.stack([np.ones(len(r)), small, big, quads], 1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, dur * 10.0, rcond=None)
 print("fit dur[0.1us] = %.1f + %.2f*small + %.2f*big + %.2f*quads" % tuple(coef))
+cost = 20 + 2 * small + 30 * big + 3 * quads                        # kernels_tile.h tile_cost
+for c0, q0 in ((400, 48), (350, 32), (600, 64), (800, 64)):
+    m = (cost >= c0) & (quads >= q0)
+    print(f"tiles that qualify for the quad split at cost >= {c0}, quads >= {q0}: {m.sum()} (HEAVY0_MAX 128); the slowest tile qualifies: {bool(m[np.argmax(dur)])}")
