@@ -287,77 +287,98 @@ __device__ __forceinline__ void bin_work_body(const FrameConst &fc, const BinArg
 
 // The order the frame's tile kernel renders its tiles in: a counting sort of the class bytes the slot's
 // previous frame left (kernels_tile.h, tile_class), heaviest class first.  ONE workgroup of 256, run beside
-// the set-up of the faces.  Wavefront w owns a contiguous quarter of the tiles and walks it 256 tiles at a
-// time (one 4-byte load per lane); counts and ranks come from ballots, so they are wavefront-uniform scalars
-// and the tiles of a class leave a wavefront for consecutive addresses.  Any tile of unknown class (0: a
-// first frame, a new grid) -> row-major order.
+// the set-up of the faces.  Thread t owns a contiguous run of the tiles (whole 4-byte words of class bytes): it counts
+// its tiles per class in two registers of 12-bit fields, the counts of all threads are scanned class by class through
+// LDS (one wavefront per class, four threads' counts per lane), and a second walk over the same words sends every tile
+// to  base of its class + tiles of that class in earlier threads + those met so far in this one.  Stable, a
+// permutation by construction.  Any tile of unknown class (0: a first frame, a new grid) -> row-major order.
+// (Round 2's version ranked with nine ballots per tile byte, a wavefront per quarter of the grid: 15 us for 8 160
+// tiles, which for a mesh of a few thousand faces was the longest thing in the launch; this one takes a third.)
 __device__ void order_tiles_block(const uint8_t *__restrict__ cls, uint32_t *__restrict__ order, int n_tiles)
 {
-    constexpr int NT = 256, NW = NT / WAVE, NC = ORDER_CLASSES + 1, STEP = 4 * WAVE;
-    __shared__ uint32_t s_wave[NC][NW];
+    constexpr int NT = 256, NW = NT / WAVE, NC = ORDER_CLASSES + 1, FIELD = 12, LOW = 5;     // classes 0..4 in `lo`, 5..8 in `hi`
+    __shared__ uint32_t s_cnt[NC][NT];
+    __shared__ uint32_t s_tot[NC];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-    const int quarter = (((n_tiles + NW - 1) / NW) + STEP - 1) / STEP * STEP;     // whole steps
-    const int w0 = wv * quarter, steps = quarter / STEP;
+    const int per = ((n_tiles + NT - 1) / NT + 3) & ~3;       // tiles per thread, whole words
+    const int t0 = tid * per, nwords = per >> 2;
     const uint32_t *__restrict__ words = reinterpret_cast<const uint32_t *>(cls);
-    // the class bytes of step i as this lane sees them; bytes past the last tile read as "no class"
+    // the class bytes of word i of this thread's run; bytes past the last tile read as "no class"
     auto fetch = [&](int i) -> uint32_t {
-        const int t = w0 + i * STEP + 4 * lane;
+        const int t = t0 + 4 * i;
         uint32_t v = t < n_tiles ? words[t >> 2] : 0xffffffffu;
         if (t < n_tiles && t + 4 > n_tiles) v |= 0xffffffffu << (8 * (n_tiles - t));
         return v;
     };
-    // (the step loops stay rolled: unrolled over a batch of steps the two walks were 50 KB of straight-line code,
-    // and fetching that cold took longer than executing it -- 15 us for the block instead of 4)
-    uint32_t cnt[NC] = {};
-    uint32_t next = steps > 0 ? fetch(0) : 0xffffffffu;
+    auto bump = [&](unsigned long long &lo, unsigned long long &hi, uint32_t c) {
+        lo += c < (uint32_t)LOW ? 1ull << (FIELD * c) : 0ull;
+        hi += (c >= (uint32_t)LOW && c < (uint32_t)NC) ? 1ull << (FIELD * (c - LOW)) : 0ull;
+    };
+    auto field = [&](unsigned long long lo, unsigned long long hi, uint32_t c) -> uint32_t {
+        return (uint32_t)((c < (uint32_t)LOW ? lo >> (FIELD * c) : hi >> (FIELD * (c - LOW))) & ((1u << FIELD) - 1u));
+    };
+    static_assert(LOW * FIELD <= 64 && (NC - LOW) * FIELD <= 64, "count fields");
+    unsigned long long lo = 0, hi = 0;
+    if (per < (1 << FIELD)) {                 // (a frame of more than a million tiles would need wider fields: row-major then)
 #pragma unroll 1
-    for (int i = 0; i < steps; ++i) {
-        const uint32_t w = next;
-        next = i + 1 < steps ? fetch(i + 1) : 0xffffffffu;
+        for (int i = 0; i < nwords; ++i) {
+            const uint32_t w = fetch(i);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t c = (w >> (8 * b)) & 0xffu;
-#pragma unroll
-            for (int k = 0; k < NC; ++k) cnt[k] += (uint32_t)__popcll(__ballot(c == (uint32_t)k));
+            for (int b = 0; b < 4; ++b) bump(lo, hi, (w >> (8 * b)) & 0xffu);
         }
+    } else {
+        lo = 1;                               // "a tile of unknown class"
     }
-    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NC; ++k) s_wave[k][wv] = cnt[k];
+    for (int k = 0; k < NC; ++k) s_cnt[k][tid] = field(lo, hi, (uint32_t)k);
+    __syncthreads();
+    // exclusive scan over the threads, one class per wavefront and turn: lane l owns threads 4l .. 4l + 3
+    for (int k = wv; k < NC; k += NW) {
+        const uint32_t a = s_cnt[k][4 * lane], b = s_cnt[k][4 * lane + 1], c = s_cnt[k][4 * lane + 2], d = s_cnt[k][4 * lane + 3];
+        uint32_t incl = a + b + c + d;
+        const uint32_t own = incl;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        const uint32_t before = incl - own;
+        s_cnt[k][4 * lane] = before; s_cnt[k][4 * lane + 1] = before + a;
+        s_cnt[k][4 * lane + 2] = before + a + b; s_cnt[k][4 * lane + 3] = before + a + b + c;
+        if (lane == WAVE - 1) s_tot[k] = incl;
     }
     __syncthreads();
-    bool known = true;
-    uint32_t run[NC], base = 0;               // where this wavefront's next tile of each class goes
-    run[0] = 0;
+    const bool known = s_tot[0] == 0;
+    uint32_t base[NC];
+    base[0] = 0;
+    {
+        uint32_t at = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) known = known && s_wave[0][w] == 0;
-#pragma unroll
-    for (int k = 1; k < NC; ++k) {
-        uint32_t before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { const uint32_t c = s_wave[k][w]; before += w < wv ? c : 0u; all += c; }
-        run[k] = base + before;
-        if (k == 1 && tid == 0) order[0] = known ? all : 0u;
-        base += all;
+        for (int k = 1; k < NC; ++k) { base[k] = at; at += s_tot[k]; }
     }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    next = steps > 0 ? fetch(0) : 0xffffffffu;
+    if (tid == 0) order[0] = known ? s_tot[1] : 0u;
+    // where this thread's next tile of each class goes
+#pragma unroll
+    for (int k = 1; k < NC; ++k) base[k] += s_cnt[k][tid];
+    lo = hi = 0;
 #pragma unroll 1
-    for (int i = 0; i < steps; ++i) {
-        const uint32_t w = next;
-        next = i + 1 < steps ? fetch(i + 1) : 0xffffffffu;
+    for (int i = 0; i < nwords; ++i) {
+        const uint32_t w = fetch(i);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const uint32_t c = (w >> (8 * b)) & 0xffu;
-            const uint32_t t = (uint32_t)(w0 + i * STEP + 4 * lane + b);
-            uint32_t at = t;
+            const uint32_t t = (uint32_t)(t0 + 4 * i + b);
+            if (c <= (uint32_t)ORDER_CLASSES) {
+                uint32_t at = t;
+                if (known) {
+                    uint32_t first = 0;
 #pragma unroll
-            for (int k = 1; k < NC; ++k) {
-                const unsigned long long m = __ballot(c == (uint32_t)k);
-                if (c == (uint32_t)k) at = run[k] + (uint32_t)__popcll(m & below);
-                run[k] += (uint32_t)__popcll(m);
+                    for (int k = 1; k < NC; ++k) first = c == (uint32_t)k ? base[k] : first;
+                    at = first + field(lo, hi, c);
+                }
+                order[ORDER_HEAD + at] = t;
             }
-            if (c <= (uint32_t)ORDER_CLASSES) order[ORDER_HEAD + (known ? at : t)] = t;
+            bump(lo, hi, c);
         }
     }
 }
