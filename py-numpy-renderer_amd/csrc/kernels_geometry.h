@@ -623,6 +623,7 @@ __device__ __forceinline__ double shfl_d(double v, int src)
 // bit-identical.  `have`: this 16-lane group has an edge (face, corner = sil_f, sil_k; list slot
 // s_idx).  Every lane of the wavefront must call it; s_poly is the wavefront's scratch.
 constexpr int QS_LANES = 16;
+constexpr uint32_t EDGE_DENSE = 0xffu;       // SetupKernArgs::edge_spread: two edges per lane (see edge_block)
 static_assert(MAX_POLY <= QS_LANES, "one polygon vertex per lane");
 
 __device__ __forceinline__ void quad_setup_group(bool have, int sil_f, int sil_k, uint32_t s_base_raw, uint32_t s_rank,
@@ -802,71 +803,103 @@ __device__ __forceinline__ void edge_block(uint32_t block)
     SETUP_ARGS();
     __shared__ double s_poly[SETUP_BLOCK / WAVE][WAVE / QS_LANES][MAX_POLY + 4][4];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-    // A wavefront sets its silhouette edges up four at a time, one round after the other, 10-15 us each.  A mesh of a few
-    // thousand edges of which one in ten is on the silhouette (c3: 7 500 edges, 120 wavefronts with five or six each)
-    // then spends two or three rounds where a large mesh (one silhouette edge in 250) spends one: for small scenes only
-    // every (1 << edge_spread)-th lane takes an edge, and there are that many more wavefronts.
+    // How many edges a lane looks at.  A wavefront sets its silhouette edges up four at a time, one round of 10-15 us
+    // after the other, so what matters is how many it FINDS:
+    //   small scenes (edge_spread s > 0): a mesh of a few thousand edges of which one in ten is on the silhouette (c3:
+    //     7 500 edges, 120 wavefronts with five or six each) spent two or three rounds -- only every (1 << s)-th lane
+    //     takes an edge, and there are that many more wavefronts;
+    //   large scenes (EDGE_DENSE): one edge in 250 is on the silhouette, the launch holds more wavefronts than fit at
+    //     once (c4: 3 128 of faces + 4 688 of edges against 5 120 places) and the edge wavefronts that wait for a place
+    //     start their chain late -- two edges per lane halve their number and still find five in one wavefront less
+    //     than once per frame.
     const uint32_t spread = ka_.edge_spread;
+    const bool dense = spread == EDGE_DENSE;
     const uint32_t slot_in_grid = block * blockDim.x + threadIdx.x;
-    const int e = (int)(slot_in_grid >> spread);
-    bool sil = false;
-    uint32_t last = 0;
-    if ((slot_in_grid & ((1u << spread) - 1u)) == 0 && e < fc.n_edges) {
+    int e[2];
+    bool want[2];
+    if (dense) {
+        e[0] = (int)(block * 2u * blockDim.x + threadIdx.x); e[1] = e[0] + (int)blockDim.x;
+        want[0] = e[0] < fc.n_edges; want[1] = e[1] < fc.n_edges;
+    } else {
+        e[0] = (int)(slot_in_grid >> spread); e[1] = 0;
+        want[0] = (slot_in_grid & ((1u << spread) - 1u)) == 0 && e[0] < fc.n_edges; want[1] = false;
+    }
+    bool sil[2] = { false, false };
+    uint32_t last[2] = { 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!want[i]) continue;
         EdgeRec r;
         if (fc.edge_compact) {
-            const EdgeRec32 c = reinterpret_cast<const EdgeRec32 *>(sa.edges)[e];
+            const EdgeRec32 c = reinterpret_cast<const EdgeRec32 *>(sa.edges)[e[i]];
             r.inc[0] = c.inc[0]; r.inc[1] = c.inc[1];
             r.extra_off = r.extra_cnt = 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) r.n[i][j] = (double)c.n[i][j];
+                for (int j = 0; j < 3; ++j) r.n[a][j] = (double)c.n[a][j];
         } else {
-            r = sa.edges[e];
+            r = sa.edges[e[i]];
         }
         uint32_t cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (r.inc[i] != 0xffffffffu &&
-                chain3(r.n[i][0], r.n[i][1], r.n[i][2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0) {
-                ++cnt; last = r.inc[i];
+        for (int a = 0; a < 2; ++a) {
+            if (r.inc[a] != 0xffffffffu &&
+                chain3(r.n[a][0], r.n[a][1], r.n[a][2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0) {
+                ++cnt; last[i] = r.inc[a];
             }
         }
         for (uint32_t k = 0; k < r.extra_cnt; ++k) {
             const uint32_t inc = sa.edge_inc[r.extra_off + k];
             const double *fn = sa.face_n + (size_t)(inc >> 2) * 4;
-            if (chain3(fn[0], fn[1], fn[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0) { ++cnt; last = inc; }
+            if (chain3(fn[0], fn[1], fn[2], fc.light_pos[0], fc.light_pos[1], fc.light_pos[2]) > 0) { ++cnt; last[i] = inc; }
         }
-        sil = (cnt & 1u) != 0;
+        sil[i] = (cnt & 1u) != 0;
     }
-    unsigned long long todo = __ballot(sil);
-    if (!todo) return;
+    unsigned long long todo0 = __ballot(sil[0]), todo1 = __ballot(sil[1]);
+    if (!(todo0 | todo1)) return;
     // the wavefront's silhouette edges get consecutive list slots with one atomic; its answer is first needed
-    // at the end of the quad set-up (the records' back references), so it is not waited for here
+    // at the end of the quad set-up (the records' slots), so it is not waited for here
+    const uint32_t found0 = (uint32_t)__popcll(todo0), found = found0 + (uint32_t)__popcll(todo1);
     uint32_t base_raw = 0;
-    if (lane == 0) base_raw = atomicAdd(&sa.ctr->n_quads, (uint32_t)__popcll(todo));
-    const uint32_t my_rank = (uint32_t)__popcll(todo & ((1ull << lane) - 1ull));
-    // quad set-up, four silhouette edges per round (one per 16-lane group)
+    if (lane == 0) base_raw = atomicAdd(&sa.ctr->n_quads, found);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t my_rank0 = (uint32_t)__popcll(todo0 & below), my_rank1 = found0 + (uint32_t)__popcll(todo1 & below);
+    // quad set-up, four silhouette edges per round (one per 16-lane group): the lanes' first edges, then their second
     const int grp = lane / QS_LANES;
-    while (todo) {
-        int src = -1;
-        unsigned long long t = todo;
-        for (int g = 0; g <= grp && t; ++g) {                       // this group takes the grp-th set bit
-            const int b = __ffsll((long long)t) - 1;
-            t &= t - 1;
-            if (g == grp) src = b;
+    while (todo0 | todo1) {
+        int src = -1, set = 0;
+        {
+            const int c0 = (int)__popcll(todo0);
+            unsigned long long t = grp < c0 ? todo0 : todo1;
+            const int nth = grp < c0 ? grp : grp - c0;
+            set = grp < c0 ? 0 : 1;
+            for (int g = 0; g <= nth && t; ++g) {                   // this group takes the nth set bit
+                const int b = __ffsll((long long)t) - 1;
+                t &= t - 1;
+                if (g == nth) src = b;
+            }
         }
-        for (int g = 0; g < WAVE / QS_LANES && todo; ++g) todo &= todo - 1;
+        for (int g = 0; g < WAVE / QS_LANES; ++g) {                  // the round's (up to) four leave the lists
+            if (todo0) todo0 &= todo0 - 1;
+            else if (todo1) todo1 &= todo1 - 1;
+        }
         const bool have = src >= 0;
-        const uint32_t ls = (uint32_t)__shfl((int)last, have ? src : 0);
-        const uint32_t rank = (uint32_t)__shfl((int)my_rank, have ? src : 0);
+        const int from = have ? src : 0;
+        const uint32_t l0 = (uint32_t)__shfl((int)last[0], from), l1 = (uint32_t)__shfl((int)last[1], from);
+        const uint32_t r0 = (uint32_t)__shfl((int)my_rank0, from), r1 = (uint32_t)__shfl((int)my_rank1, from);
+        const uint32_t ls = set ? l1 : l0, rank = set ? r1 : r0;
         quad_setup_group(have, (int)(ls >> 2), (int)(ls & 3u), base_raw, rank, s_poly[wv]);
     }
-    const uint32_t my_slot = (uint32_t)__shfl((int)base_raw, 0) + my_rank;
+    const uint32_t base = (uint32_t)__shfl((int)base_raw, 0);
     const SetupArgs &sa2 = kernargs<SetupKernArgs>().sa;
-    if (sil && my_slot < sa2.quad_cap) {
-        sa2.sil_edges[my_slot * 2 + 0] = (int32_t)(last >> 2);      // the host maps the face back to its model
-        sa2.sil_edges[my_slot * 2 + 1] = (int32_t)(last & 3u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t my_slot = base + (i ? my_rank1 : my_rank0);
+        if (sil[i] && my_slot < sa2.quad_cap) {
+            sa2.sil_edges[my_slot * 2 + 0] = (int32_t)(last[i] >> 2);      // the host maps the face back to its model
+            sa2.sil_edges[my_slot * 2 + 1] = (int32_t)(last[i] & 3u);
+        }
     }
 }
 

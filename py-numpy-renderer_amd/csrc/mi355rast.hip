@@ -656,10 +656,12 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         const unsigned face_blocks = fc.n_faces > 0 ? blocks_for(fc.n_faces, SETUP_BLOCK) : 0u;
         // small meshes: one edge per 2 / 4 lanes, so that a wavefront rarely finds more silhouette edges than one round
         // of its quad set-up takes (kernels_geometry.h, edge_block)
-        static const int spread_env = getenv("MR_EDGE_SPREAD") ? atoi(getenv("MR_EDGE_SPREAD")) : -1;
-        const unsigned spread = spread_env >= 0 ? (unsigned)std::min(spread_env, 4)
-                              : fc.n_edges <= (1 << 15) ? 2u : fc.n_edges <= (1 << 17) ? 1u : 0u;
-        const unsigned edge_blocks = (shadows && fc.n_edges > 0) ? blocks_for((long long)fc.n_edges << spread, SETUP_BLOCK) : 0u;
+        static const int spread_env = getenv("MR_EDGE_SPREAD") ? atoi(getenv("MR_EDGE_SPREAD")) : -2;     // -1: dense
+        const bool dense = spread_env == -1 || (spread_env == -2 && fc.n_edges > (1 << 17));
+        const unsigned spread = dense ? EDGE_DENSE : spread_env >= 0 ? (unsigned)std::min(spread_env, 4)
+                              : fc.n_edges <= (1 << 15) ? 2u : 1u;
+        const unsigned edge_blocks = !(shadows && fc.n_edges > 0) ? 0u
+                                   : dense ? blocks_for(fc.n_edges, 2 * SETUP_BLOCK) : blocks_for((long long)fc.n_edges << spread, SETUP_BLOCK);
         SetupKernArgs ska;
         ska.fc = fc; ska.sa = sa; ska.bins = ba; ska.face_blocks = face_blocks; ska.edge_spread = spread;
         if (vertex_mfma)
