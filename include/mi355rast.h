@@ -318,6 +318,14 @@ int mr_read_silhouette(mr_scene *scene, int32_t *out_triples, int32_t cap);
 #define MR_TILE_RECORD_WORDS 12
 int mr_debug_read_tile_records(mr_scene *scene, uint32_t *out, int32_t cap_tiles);
 
+/* Diagnostic: how many 64-face clusters the last frame's set-up kernel dropped whole (off the screen, off this device's
+ * rows, or -- when the frame culls back faces -- turned away from the camera) before reading a face of them.  Counted
+ * only when the environment has MR_CLUSTER_CULL=count; 0 otherwise.  The faces that ARE set up, and the frame, do not
+ * depend on it.  By default clusters are culled on partial frames (a row band, stripes), where most of them go, and not
+ * on whole frames, where the test costs more than it saves; MR_CLUSTER_CULL=0 / 1 / box force it off / on /
+ * on with the screen and row test only. */
+int mr_debug_clusters_culled(mr_scene *scene);
+
 /* Diagnostics: the order in which the most recent frame's tile kernel took its tiles (entry b = the tile
  * of workgroup b): heaviest first by the estimate the slot's previous frame left, row-major for a first
  * frame or a new tile grid.  Always a permutation of 0 .. n_tiles-1.  Returns the number of tiles. */

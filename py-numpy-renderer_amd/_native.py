@@ -109,6 +109,7 @@ _PROTOTYPES = {
                                         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mr_host_overlay_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mr_debug_read_tile_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "mr_debug_clusters_culled": (C.c_int, [C.c_void_p]),
     "mr_debug_read_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_last_error": (C.c_char_p, []),
 }
@@ -577,6 +578,10 @@ class DeviceRenderer:
         out = np.empty((max(n, 1), TILE_RECORD_WORDS), dtype=np.uint32)
         _check(self.lib.mr_debug_read_tile_records(self.handle, out.ctypes.data, n), "mr_debug_read_tile_records")
         return out[:n]
+
+    def clusters_culled(self):
+        """Clusters of 64 faces the last frame's set-up dropped whole (counted only under MR_CLUSTER_CULL=count)."""
+        return int(_check(self.lib.mr_debug_clusters_culled(self.handle), "mr_debug_clusters_culled"))
 
     def read_tile_order(self):
         """The order in which the last frame's tile kernel took its tiles: (n_tiles,) uint32."""

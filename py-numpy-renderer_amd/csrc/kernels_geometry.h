@@ -301,6 +301,7 @@ struct SetupArgs {
     Counters *ctr;
     const uint8_t *tile_class;       // what the slot's previous frame left (kernels_tile.h, tile_class) ...
     uint32_t *order;                 // ... and the tile order made of it for this frame's tile kernel
+    const ClusterRec *clusters;      // static: one per 64 consecutive faces (cluster_culled)
     const EdgeRec *edges;            // static unique-edge table (EdgeRec32[] when fc.edge_compact)
     const uint32_t *edge_inc;        // incidences beyond an edge's first two
     const double *face_n;            // static face normals (for those)
@@ -464,6 +465,72 @@ __device__ __forceinline__ int tri_setup_record(int f, int32_t material, uint8_t
     return count_here ? 1 : 3;
 }
 
+__device__ __forceinline__ double shfl_d(double v, int src)
+{
+    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
+}
+
+// Does the per-face work of cluster `cid` (the 64 faces of one wavefront) come to nothing for every one of them?
+// Wavefront-uniform; conservative against the per-face tests of tri_setup_one / tri_setup_record:
+//   * all eight corners of the cluster's box are in front of the camera (clip w > 0: the projection is then monotone
+//     along every edge of the box, so the faces' screen coordinates lie between the corners'), and either
+//   * the corners' screen box, widened by two pixels, holds no sample of the frame or none on this device's rows --
+//     every face's own pixel box is inside it, so bound_box / tile_span would have dropped each of them -- or
+//   * the frame culls back faces and every normal of the cluster's cone points away from the camera even from the
+//     corner of the box where it points away least, with a margin of 1e-4 of the distance (the per-face test decides on
+//     the sign of a screen-space area evaluated in float64: its rounding is ten orders of magnitude below that).
+// Faces it lets through are set up exactly as before; faces it stops would have been stopped one by one.
+__device__ __forceinline__ bool cluster_culled(uint32_t cid)
+{
+    SETUP_ARGS();
+    const int lane = threadIdx.x & (WAVE - 1);
+    const ClusterRec c = sa.clusters[__builtin_amdgcn_readfirstlane(cid)];
+    // corner (lane & 7) of the box through the frame's matrices
+    const double v[4] = { (double)((lane & 1) ? c.hi[0] : c.lo[0]), (double)((lane & 2) ? c.hi[1] : c.lo[1]),
+                          (double)((lane & 4) ? c.hi[2] : c.lo[2]), 1.0 };
+    const double cx = row_times_col(v, fc.mvp, 0), cy = row_times_col(v, fc.mvp, 1), cz = row_times_col(v, fc.mvp, 2),
+                 cw = row_times_col(v, fc.mvp, 3);
+    double r = __builtin_amdgcn_rcp(cw);
+    r = fma(fma(-cw, r, 1.0), r, r);
+    const double nd[4] = { cx * r, cy * r, cz * r, 1.0 };
+    double x_lo = row_times_col(nd, fc.viewport, 0), y_lo = row_times_col(nd, fc.viewport, 1), w_lo = cw;
+    double x_hi = x_lo, y_hi = y_lo, w_hi = cw;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const double a = shfl_d(x_lo, lane ^ off), b = shfl_d(x_hi, lane ^ off), d = shfl_d(y_lo, lane ^ off),
+                     e = shfl_d(y_hi, lane ^ off), f = shfl_d(w_lo, lane ^ off), g = shfl_d(w_hi, lane ^ off);
+        x_lo = a < x_lo ? a : x_lo; x_hi = b > x_hi ? b : x_hi;
+        y_lo = d < y_lo ? d : y_lo; y_hi = e > y_hi ? e : y_hi;
+        w_lo = f < w_lo ? f : w_lo; w_hi = g > w_hi ? g : w_hi;
+    }
+    // (anything not finite fails these comparisons: no culling then)
+    if (!(w_lo > 1e-6 && w_lo > 1e-9 * w_hi && w_hi < 1e300)) return false;
+    if (!(fabs(x_lo) < 1e9 && fabs(x_hi) < 1e9 && fabs(y_lo) < 1e9 && fabs(y_hi) < 1e9)) return false;
+    {
+        const double xs[2] = { x_lo - 2.0, x_hi + 2.0 }, ys[2] = { y_lo - 2.0, y_hi + 2.0 };
+        int bx0, bx1, by0, by1;
+        if (!bound_box(xs, ys, 2, fc.width, fc.height, bx0, bx1, by0, by1)) return true;
+        TileSpan own;
+        if (!tile_span(fc, bx0, bx1, by0, by1, own)) return true;
+    }
+    if (!(fc.cluster_cull & CC_CONE) || !fc.backface_culling || !(c.cos_half >= 0.f)) return false;
+    // the cone: s * n . (a - eye) > 0 for every face normal n and face point a of the cluster
+    const double s = (fc.cluster_cull & CC_NEGATIVE) ? -1.0 : 1.0;
+    const double ctr[3] = { 0.5 * ((double)c.lo[0] + (double)c.hi[0]), 0.5 * ((double)c.lo[1] + (double)c.hi[1]),
+                            0.5 * ((double)c.lo[2] + (double)c.hi[2]) };
+    const double hx = 0.5 * ((double)c.hi[0] - (double)c.lo[0]), hy = 0.5 * ((double)c.hi[1] - (double)c.lo[1]),
+                 hz = 0.5 * ((double)c.hi[2] - (double)c.lo[2]);
+    const double radius = sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-6);
+    const double d[3] = { s * (ctr[0] - fc.cull_eye[0]), s * (ctr[1] - fc.cull_eye[1]), s * (ctr[2] - fc.cull_eye[2]) };
+    const double dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double along = d[0] * (double)c.axis[0] + d[1] * (double)c.axis[1] + d[2] * (double)c.axis[2];      // |d| cos(theta)
+    const double across2 = dist2 - along * along;
+    const double across = across2 > 0 ? sqrt(across2) * (1.0 + 1e-6) : 0.0;                                    // |d| sin(theta)
+    // least of n . d over the cone is |d| cos(theta + alpha); a face point is at most `radius` from the centre
+    const double least = along * (double)c.cos_half - across * (double)c.sin_half - radius;
+    return least > 1e-4 * sqrt(dist2) + 1e-9 && dist2 < 1e300;
+}
+
 constexpr int SETUP_BLOCK = 256;
 
 // Face workgroup: one face per lane.  The list of faces whose survivor count needs a wavefront and
@@ -479,7 +546,18 @@ __device__ __forceinline__ void tri_setup_block(uint32_t block)
     unsigned int covered = 0;
     PrimBox pb = { 0, 0, 0, 0 };
     bool clip = false;
-    const int r = f < kernargs<SetupKernArgs>().fc.n_faces ? tri_setup_one<PRE_XFORM>(f, covered, pb, clip) : 0;
+    bool go;
+    {
+        const FrameConst &fc0 = kernargs<SetupKernArgs>().fc;
+        go = f < fc0.n_faces;
+        // (the cluster of a wavefront's faces: both are 64 consecutive faces)
+        if (fc0.cluster_cull && (block * blockDim.x + wv * WAVE) < (uint32_t)fc0.n_faces &&
+            cluster_culled(block * (blockDim.x / WAVE) + (uint32_t)wv)) {
+            go = false;
+            if (lane == 0 && (fc0.cluster_cull & CC_COUNT)) atomicAdd(&kernargs<SetupKernArgs>().sa.ctr->pad0[0], 1u);   // (MR_CLUSTER_CULL=count: mr_debug_clusters_culled)
+        }
+    }
+    const int r = go ? tri_setup_one<PRE_XFORM>(f, covered, pb, clip) : 0;
     SETUP_ARGS();                                                // phase 3: the tile lists, the workgroup's epilogue
     // the face's own tile lists (kernels_bin.h)
     bin_triangles(fc, bins, (r & 1) != 0, (uint32_t)f, pb, clip);
@@ -604,10 +682,6 @@ __device__ __forceinline__ double plane_dot(const double *P, const double *q)
     return chain4(P[0], P[1], P[2], P[3], q[0], q[1], q[2], q[3]);
 }
 
-__device__ __forceinline__ double shfl_d(double v, int src)
-{
-    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
-}
 
 // Shadow-quad set-up: extrusion away from the light, Sutherland-Hodgman clipping against the
 // camera frustum, projection, plane equation and pixel box (obj/core.py:610-622,

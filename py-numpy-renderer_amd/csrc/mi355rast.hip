@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -171,6 +172,7 @@ struct mr_scene {
     DevBuf d_edges32;                        // the compact edge table, when the scene allows it
     bool edge_compact = false;
     DevBuf d_face_pos, d_face_attr;          // static per face (rast_types.h, FacePosT / FaceAttr), built by commit()
+    DevBuf d_clusters;                       // static per 64 faces (rast_types.h, ClusterRec), built by commit()
     bool pos32 = false;                      // d_face_pos holds FacePos32 (every model's vertices are float32)
     bool has_no_depth = false;               // some model has depth_test == False (what a frame asks once per scene, not once per frame)
     // debug-frustum overlay: the level lists (host_overlay.h, OverlayLevels) in ONE device buffer, filled with one
@@ -300,6 +302,59 @@ std::vector<float> gamma_thresholds()
     return lut;
 }
 
+// The static cluster records (rast_types.h, ClusterRec): bounding box and normal cone of every 64 consecutive faces.
+std::vector<mr::ClusterRec> build_clusters(const mr_scene *sc)
+{
+    const size_t nf = sc->faces.size() / 12, nc = (nf + mr::CLUSTER_FACES - 1) / mr::CLUSTER_FACES;
+    std::vector<mr::ClusterRec> out(nc);
+    auto down = [](double x) { float f = (float)x; return (double)f > x ? std::nextafter(f, -INFINITY) : f; };
+    auto up = [](double x) { float f = (float)x; return (double)f < x ? std::nextafter(f, INFINITY) : f; };
+    for (size_t c = 0; c < nc; ++c) {
+        mr::ClusterRec r;
+        std::memset(&r, 0, sizeof r);
+        double lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY }, sum[3] = { 0, 0, 0 };
+        bool boxed = true, coned = true;
+        const size_t f0 = c * mr::CLUSTER_FACES, f1 = std::min(nf, f0 + mr::CLUSTER_FACES);
+        std::vector<std::array<double, 3>> normals;
+        normals.reserve(f1 - f0);
+        for (size_t f = f0; f < f1; ++f) {
+            const double *v[3];
+            for (int k = 0; k < 3; ++k) {
+                v[k] = &sc->verts[(size_t)sc->faces[f * 12 + k * 4] * 4];
+                if (!(v[k][3] == 1.0)) boxed = false;                     // (a homogeneous coordinate other than 1: no box)
+                for (int j = 0; j < 3; ++j) { lo[j] = std::min(lo[j], v[k][j]); hi[j] = std::max(hi[j], v[k][j]); if (!std::isfinite(v[k][j])) boxed = false; }
+            }
+            const double a[3] = { v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2] };
+            const double b[3] = { v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2] };
+            double n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+            const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (!(l > 0) || !std::isfinite(l)) { coned = false; continue; }
+            for (int j = 0; j < 3; ++j) { n[j] /= l; sum[j] += n[j]; }
+            normals.push_back({ n[0], n[1], n[2] });
+        }
+        if (boxed) {
+            for (int j = 0; j < 3; ++j) { r.lo[j] = down(lo[j]); r.hi[j] = up(hi[j]); }
+        } else {
+            for (int j = 0; j < 3; ++j) { r.lo[j] = NAN; r.hi[j] = NAN; }      // never culled: every comparison fails
+        }
+        r.cos_half = -2.f; r.sin_half = 1.f;
+        const double sl = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+        if (coned && sl > 1e-6 * (double)(f1 - f0)) {
+            double least = 1.0;
+            for (const auto &n : normals) least = std::min(least, (n[0] * sum[0] + n[1] * sum[1] + n[2] * sum[2]) / sl);
+            least -= 1e-6;
+            if (least > 0.05) {                                             // a cone wider than ~87 degrees never culls anything
+                for (int j = 0; j < 3; ++j) r.axis[j] = (float)(sum[j] / sl);
+                // the axis as stored (float32) is not the axis the dots were taken with: 1e-6 covers it
+                r.cos_half = (float)(least - 1e-6);
+                r.sin_half = (float)std::min(1.0, std::sqrt(std::max(0.0, 1.0 - (double)r.cos_half * (double)r.cos_half)) + 1e-6);
+            }
+        }
+        out[c] = r;
+    }
+    return out;
+}
+
 int commit(mr_scene *sc)
 {
     if (!sc->dirty) return MR_OK;
@@ -343,6 +398,13 @@ int commit(mr_scene *sc)
     }
     HIP_TRY(sc->d_face_pos.ensure(std::max<size_t>((size_t)nf * (sc->pos32 ? sizeof(mr::FacePos32) : sizeof(mr::FacePos64)), 16)));
     HIP_TRY(sc->d_face_attr.ensure(std::max<size_t>((size_t)nf * sizeof(mr::FaceAttr), 16)));
+    {
+        const std::vector<mr::ClusterRec> clusters = build_clusters(sc);
+        HIP_TRY(sc->d_clusters.ensure(std::max<size_t>(clusters.size() * sizeof(mr::ClusterRec), 64)));
+        if (!clusters.empty())
+            HIP_TRY(hipMemcpyAsync(sc->d_clusters.p, clusters.data(), clusters.size() * sizeof(mr::ClusterRec), hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));            // (the vector goes out of scope)
+    }
     if (nf > 0 && sc->pos32)
         hipLaunchKernelGGL(mr::k_face_static<float>, dim3((nf + 255) / 256), dim3(256), 0, g_stream, nf, sc->d_faces.as<int32_t>(),
                            sc->d_face_flags.as<uint8_t>(), sc->d_verts.as<double>(), sc->d_uv.as<float>(), sc->d_normals.as<float>(),
@@ -443,6 +505,51 @@ mr::FrameConst make_const(const mr_scene *sc, const mr_frame_desc *fr)
     fc.same_clip = memcmp(fr->mvp, fr->debug_mvp, sizeof(fr->mvp)) == 0 ? 1 : 0;
     fc.edge_compact = sc->edge_compact ? 1 : 0;
     fc.pos32 = sc->pos32 ? 1 : 0;
+    // cluster culling (kernels_geometry.h, cluster_culled).  Not when the caller wants per-face status or the fragment
+    // counters: those see faces one by one.  The back-face cone needs the camera's centre of projection E and the sign
+    // convention of obj/triangular.py:47-48 in world space: with e the null vector of MVP's (x, y, w) columns, e = ew (E, 1),
+    // the screen-space area of a face whose corners are all in front of the camera has the sign of
+    // det(viewport xy) * ew * n . (E - a)  for its world normal n = (b - a) x (c - a)  (Cauchy-Binet on the 3x4 by 4x3
+    // product; checked against the per-face test on random cameras and triangles, tests/test_host_api.py).
+    {
+        const char *env = getenv("MR_CLUSTER_CULL");         // (looked up per frame: the tests switch it)
+        // Measured on MI355X (round 3, A/B on one box): on a whole frame the test in front of every wavefront's first
+        // load costs more than the 40 % of c4's face wavefronts it ends are worth -- the face half is not what the
+        // launch waits for -- quoted regime c4 +2.5 %, c5 +0.8 %; on one rank's rows of a split frame, where most
+        // clusters go, set-up -3 us (c5, a rank of eight).  So: on for partial frames, off for whole ones;
+        // MR_CLUSTER_CULL=0 / 1 / box / count force it off / on / boxes only / on and counted.
+        const bool partial = fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1;
+        int mode = partial ? mr::CC_BOX | mr::CC_CONE : 0;
+        if (env && !strcmp(env, "0")) mode = 0;
+        if (env && (!strcmp(env, "1") || !strcmp(env, "count"))) mode = mr::CC_BOX | mr::CC_CONE;
+        if (env && !strcmp(env, "box")) mode = mr::CC_BOX;
+        if (fr->flags & (MR_FRAME_FACE_STATUS | MR_FRAME_COUNTERS)) mode = 0;
+        if (mode & mr::CC_CONE) {
+            const double *m = fr->mvp, *vp = fr->viewport;
+            auto P = [&](int r, int c) { return m[r * 4 + (c == 2 ? 3 : c)]; };       // columns x, y, w
+            double e[4];
+            for (int i = 0; i < 4; ++i) {
+                int r[3], k = 0;
+                for (int j = 0; j < 4; ++j) if (j != i) r[k++] = j;
+                const double det = P(r[0], 0) * (P(r[1], 1) * P(r[2], 2) - P(r[1], 2) * P(r[2], 1))
+                                 - P(r[0], 1) * (P(r[1], 0) * P(r[2], 2) - P(r[1], 2) * P(r[2], 0))
+                                 + P(r[0], 2) * (P(r[1], 0) * P(r[2], 1) - P(r[1], 1) * P(r[2], 0));
+                e[i] = (i & 1) ? -det : det;
+            }
+            const double det_v = vp[0] * vp[5] - vp[1] * vp[4];
+            const double big = std::max(std::max(fabs(e[0]), fabs(e[1])), std::max(fabs(e[2]), fabs(e[3])));
+            const bool ok = std::isfinite(big) && big > 0 && fabs(e[3]) > 1e-9 * big && std::isfinite(det_v) && det_v != 0 &&
+                            vp[8] == 0 && vp[9] == 0;          // (an orthographic camera has no centre: the boxes only)
+            if (ok) {
+                for (int j = 0; j < 3; ++j) fc.cull_eye[j] = e[j] / e[3];
+                if (det_v * e[3] < 0) mode |= mr::CC_NEGATIVE;
+            } else {
+                mode &= ~mr::CC_CONE;
+            }
+        }
+        if (env && !strcmp(env, "count") && mode) mode |= mr::CC_COUNT;
+        fc.cluster_cull = mode;
+    }
     fc.specular_strength = fr->specular_strength;
     fc.att_constant = fr->att_constant; fc.att_linear = fr->att_linear; fc.att_quadratic = fr->att_quadratic;
     fc.spot_edge0 = fr->spot_edge0; fc.spot_edge1 = fr->spot_edge1;
@@ -641,6 +748,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     sa.verts = sc->d_verts.as<double>(); sa.uv = sc->d_uv.as<float>(); sa.normals = sc->d_normals.as<float>();
     sa.vout = fs->d_vout.as<VertexOut>(); sa.vclip = fs->d_vclip.as<VertexClip>();
     sa.face_pos = sc->d_face_pos.p;
+    sa.clusters = sc->d_clusters.as<mr::ClusterRec>();
     sa.tris = fs->d_tris.as<TriRec>(); sa.clips = fs->d_clips.as<TriClip>();
     sa.status = fs->d_status.as<uint8_t>(); sa.count_list = fs->d_count_list.as<uint32_t>(); sa.ctr = ctr;
     sa.edges = sc->edge_compact ? reinterpret_cast<const EdgeRec *>(sc->d_edges32.p) : sc->d_edges.as<EdgeRec>(); sa.edge_inc = sc->d_edge_inc.as<uint32_t>(); sa.face_n = sc->d_face_n.as<double>();
@@ -953,7 +1061,7 @@ void mr_scene_destroy(mr_scene *sc)
     mr_scene_clear(sc);
     DevBuf *bufs[] = { &sc->d_verts, &sc->d_uv, &sc->d_normals, &sc->d_faces, &sc->d_face_flags, &sc->d_materials,
                        &sc->d_textures, &sc->d_edges, &sc->d_edges32, &sc->d_edge_inc, &sc->d_face_n, &sc->d_sky, &sc->d_gamma,
-                       &sc->d_face_pos, &sc->d_face_attr,
+                       &sc->d_face_pos, &sc->d_face_attr, &sc->d_clusters,
                        };
     for (DevBuf *b : bufs) b->release();
     for (auto &fs : sc->slots) fs->release();
@@ -1483,6 +1591,17 @@ int mr_debug_read_tile_records(mr_scene *sc, uint32_t *out, int32_t cap_tiles)
     static_assert(mr::TILE_REC == MR_TILE_RECORD_WORDS, "tile record size is part of the ABI");
     if (n > 0) HIP_TRY(hipMemcpy(out, fs->d_tile_stats.p, (size_t)n * mr::TILE_REC * 4, hipMemcpyDeviceToHost));
     return fs->last_n_tiles;
+}
+
+int mr_debug_clusters_culled(mr_scene *sc)
+{
+    FrameSlot *fs = last_slot(sc);
+    if (!fs) return MR_E_INVALID;
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = fetch_counters(sc, fs, false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(fs->stream));
+    return (int)fs->h_counters->pad0[0];
 }
 
 int mr_debug_read_tile_order(mr_scene *sc, uint32_t *out, int32_t cap_tiles)

@@ -66,6 +66,12 @@ struct FrameConst {
     int32_t sky_size;            // cubemap face size
     int32_t has_no_depth;        // some model has depth_test == False (the tile kernel then runs its second look at the big pairs)
     double sky_rays[18];         // their un-projected corner rays [t][v][xyz]
+    // cluster culling (ClusterRec), CC_* bits: 0 off; CC_BOX the clusters' screen boxes against the screen and this
+    // device's rows; CC_CONE also the back-face cone, a face being culled when  s * n . (a - cull_eye) > 0  with
+    // s = -1 if CC_NEGATIVE else +1; CC_COUNT count the culled clusters (a diagnostic)
+    int32_t cluster_cull;
+    int32_t pad_cc;
+    double cull_eye[3];          // the camera's centre of projection in world space (the null vector of MVP's x, y, w columns)
 };
 
 // Output of the optional stand-alone vertex kernel (k_vertex_mfma): everything
@@ -107,6 +113,21 @@ static_assert(sizeof(TriRec) == 144, "TriRec layout");
 // survive the cull three uv and three normal gathers more and a 176-byte attribute record written per frame:
 // a chain of dependent trips to memory that was most of the set-up kernel's 25 us), and shading reads the same
 // records instead of a per-frame copy.  Positions are float32 when every model's vertices are (FrameConst::pos32).
+// STATIC per 64 consecutive faces (one wavefront of a face workgroup), built when the scene is committed: the faces'
+// world-space bounding box (float32, rounded outwards) and the cone their unit normals lie in.  A wavefront of k_setup
+// whose cluster is entirely off the screen, off this device's rows or -- when the frame culls back faces -- turned
+// away from the camera ends before it has read a face (kernels_geometry.h, cluster_culled): conservative, so the faces
+// that are set up, and their order-free results, are exactly those of the per-face tests.
+struct alignas(16) ClusterRec {
+    float lo[3], hi[3];
+    float axis[3];               // cone axis (unit); cos_half < -1: no cone (a degenerate face, or normals more than 90 degrees apart)
+    float cos_half, sin_half;    // every face normal n of the cluster has n . axis >= cos_half
+    uint32_t pad[5];
+};
+static_assert(sizeof(ClusterRec) == 64, "ClusterRec layout");
+constexpr int CLUSTER_FACES = 64;
+constexpr int CC_BOX = 1, CC_CONE = 2, CC_NEGATIVE = 4, CC_COUNT = 8;
+
 template <class T>
 struct alignas(16) FacePosT {
     T v[3][4];                   // world-space corners (x, y, z, w)

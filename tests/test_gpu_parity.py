@@ -590,3 +590,43 @@ def test_pipelined_frames_equal_synchronous_ones(api):
         scene.camera, scene.debug_camera = cam, dbg
         assert np.array_equal(got[k], scene.render()), f"small lists: frame {k} differs"
     scene.close()
+
+
+@pytest.mark.parametrize("name", ["c4_torus200k_1080p", "diablo_floor_small", "torus_skybox_small", "tetra_ortho", "diablo_closeup_noclip"])
+def test_cluster_culling_changes_nothing_but_the_work(api, name, monkeypatch):
+    """k_setup drops whole 64-face clusters that are off the screen, off the device's rows or turned away from the
+    camera before reading a face of them (cluster_culled): the frame, the z-buffer, the winners and the set-up counts
+    must be those of the per-face tests, on whole frames and on one rank's rows, and on a closed mesh a good part of
+    the clusters must actually go."""
+    scene = scenes.build(api, name)
+    backend = scene._backend()
+    shadows = name not in scenes.NO_SHADOW
+    results = {}
+    for mode in ("0", "count", "box"):
+        monkeypatch.setenv("MR_CLUSTER_CULL", mode)
+        full = backend.render(scene, shadows=shadows, counters=False, keep_buffers=True).copy()
+        culled = backend.clusters_culled()
+        taps = (backend.read_z().copy(), backend.read_winner().copy(), backend.read_stencil().copy())
+        stats = {k: backend.last_stats[k] for k in ("n_faces_setup", "n_quads", "n_quads_drawn", "tri_bin_entries", "quad_bin_entries")}
+        h = full.shape[0]
+        band = backend.render(scene, shadows=shadows, counters=False, row_band=(h // 4, h // 2)).copy()
+        band_culled = backend.clusters_culled()
+        stripe = backend.render(scene, shadows=shadows, counters=False, stripe=(1, 3)).copy()
+        results[mode] = (full, taps, stats, band, stripe, culled, band_culled)
+    ref = results["0"]
+    assert ref[5] == 0 and ref[6] == 0
+    monkeypatch.delenv("MR_CLUSTER_CULL")           # the default: on for part of a frame, off for a whole one
+    assert np.array_equal(backend.render(scene, shadows=shadows, counters=False, row_band=(h // 4, h // 2)), ref[3])
+    assert np.array_equal(backend.render(scene, shadows=shadows, counters=False), ref[0])
+    for mode in ("count", "box"):
+        got = results[mode]
+        assert np.array_equal(got[0], ref[0]), mode
+        for a, b in zip(got[1], ref[1]):
+            assert np.array_equal(a, b, equal_nan=True), mode
+        assert got[2] == ref[2], mode
+        assert np.array_equal(got[3], ref[3]) and np.array_equal(got[4], ref[4]), mode
+    n_clusters = -(-sum(len(m._faces) for m in scene.models) // 64)
+    if name == "c4_torus200k_1080p":
+        assert results["count"][5] > 0.25 * n_clusters, (results["count"][5], n_clusters)      # back faces of the torus
+        assert results["count"][6] > results["count"][5]                                     # and what is not on the band's rows
+    scene.close()
