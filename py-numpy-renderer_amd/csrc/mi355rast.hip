@@ -787,7 +787,8 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
         // memory and a returning atomic, so the kernel lasts as many of those chains as a wavefront has items (c4: 512
         // workgroups 12.7 us, 1 280 11.5; c5: 25.0 -> 19.0; quoted regime c4 -1.5 %)
         const unsigned work_blocks = work_blocks_env ? work_blocks_env : 1280;
-        const unsigned count_blocks = fc.n_faces > 0 ? std::min(512u, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
+        static const unsigned count_blocks_env = [] { const char *e = getenv("MR_COUNT_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
+        const unsigned count_blocks = fc.n_faces > 0 ? std::min(count_blocks_env, blocks_for((long long)fc.n_faces * WAVE, 256)) : 0u;
         hipLaunchKernelGGL(k_bin_work, dim3(count_blocks + work_blocks), dim3(256), 0, stream, fc, ba,
                            fs->d_count_list.as<uint32_t>(), fs->d_tris.as<TriRec>(),
                            fs->d_clips.as<TriClip>(), fs->d_status.as<uint8_t>(), ctr, count_blocks);
