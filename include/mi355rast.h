@@ -261,6 +261,16 @@ void mr_host_free(void *p);
  * reproduce bit for bit.  The Python mirror builds its matrices, planes and overlay polygons with it. */
 void mr_host_matmul_chain(const double *a, const double *b, double *out, int32_t m, int32_t k, int32_t p);
 
+/* Host arithmetic too: what Scene.render() derives from a camera that moved, in one call -- look-at = translate @
+ * rotate, MVP = look-at @ projection (obj/core.py:383-405, obj/transformation.py:57-110) and the six normalised
+ * frustum planes of the MVP (obj/plane_intersection.py:43-56), with the operation order of the Python mirror (scalar
+ * look-at axes, products as ascending fma chains).  eye / center / up are the arguments of look_at_rotate_lh|rh (the
+ * reference passes the camera's centre as eye and its position as centre), position the camera's position,
+ * projection the 4 x 4 projection matrix (row vectors), lh != 0 the left-handed rotation.  Outputs: lookat (4 x 4),
+ * mvp (4 x 4), planes (6 x 4: left, right, bottom, top, near, far). */
+void mr_host_camera_constants(const double *eye, const double *center, const double *up, const double *position,
+                              const double *projection, int32_t lh, double *lookat, double *mvp, double *planes);
+
 /* Host arithmetic too: the statement lists of the debug-camera frustum overlay (what mr_scene_set_overlay takes),
  * from the frustum's eight corners (8 x 4, already divided by w: CUBE @ inv(debug MVP), obj/frustums.py:52-53), the
  * viewing camera's six planes (6 x 4), its MVP and viewport (4 x 4, row vectors), near / far, and whether the

@@ -61,6 +61,21 @@ def _fast_matmul():
     return _native_matmul
 
 
+_native_camera = None        # mr_host_camera_constants of the HIP library, or False
+
+
+def camera_constants():
+    """The library's one-call look-at / MVP / frustum planes (``core.TransformationMatrixMixin``), if it is built."""
+    global _native_camera
+    if _native_camera is None:
+        try:
+            from ._native import load_library
+            _native_camera = load_library().mr_host_camera_constants
+        except Exception:
+            _native_camera = False
+    return _native_camera
+
+
 def matmul_chain(a, b):
     """(M,K) @ (K,P) in float64 with every output element an ascending-k fma chain."""
     a = np.asarray(a, dtype=np.float64)

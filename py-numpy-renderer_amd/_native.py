@@ -110,6 +110,7 @@ _PROTOTYPES = {
     "mr_host_overlay_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mr_debug_read_tile_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_debug_clusters_culled": (C.c_int, [C.c_void_p]),
+    "mr_host_camera_constants": (None, [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3),
     "mr_debug_read_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mr_last_error": (C.c_char_p, []),
 }

@@ -1394,6 +1394,45 @@ void mr_host_matmul_chain(const double *a, const double *b, double *out, int32_t
         }
 }
 
+// Host arithmetic: everything Scene.render() derives from a camera that moved, in one call (obj/core.py:383-405,
+// obj/transformation.py:57-110, obj/plane_intersection.py:43-56, as the Python mirror spells them: _look_at_axes with
+// scalar arithmetic, products as ascending fma chains): look-at = translate @ rotate, MVP = look-at @ projection, and
+// the six normalised frustum planes of the MVP.  `eye`, `center`, `up` are the ARGUMENTS of look_at_rotate_* (the
+// reference passes the camera's centre as eye and its position as centre), `position` the camera's position (the
+// translation), `lh` the handedness of the rotation.  Bit-identical to the NumPy path (tests/test_host_api.py).
+void mr_host_camera_constants(const double *eye, const double *center, const double *up, const double *position,
+                              const double *projection, int32_t lh, double *lookat, double *mvp, double *planes)
+{
+    auto unit3 = [](const double v[3], double o[3]) {
+        double l = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        if (l == 0) l = 1.0;
+        for (int j = 0; j < 3; ++j) o[j] = v[j] / l;
+    };
+    auto cross3 = [](const double a[3], const double b[3], double o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    const double d[3] = { center[0] - eye[0], center[1] - eye[1], center[2] - eye[2] };
+    double forward[3], right[3], c[3], new_up[3];
+    unit3(d, forward);
+    cross3(up, forward, c);
+    unit3(c, right);
+    cross3(forward, right, new_up);
+    double rot[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 }, tr[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    for (int r = 0; r < 3; ++r) { rot[r * 4 + 0] = right[r]; rot[r * 4 + 1] = new_up[r]; rot[r * 4 + 2] = lh ? -forward[r] : forward[r]; }
+    for (int j = 0; j < 3; ++j) tr[12 + j] = -position[j];
+    mr_host_matmul_chain(tr, rot, lookat, 4, 4, 4);
+    mr_host_matmul_chain(lookat, projection, mvp, 4, 4, 4);
+    for (int axis = 0; axis < 3; ++axis)
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            double pl[4];
+            for (int r = 0; r < 4; ++r) pl[r] = sgn ? mvp[r * 4 + 3] - mvp[r * 4 + axis] : mvp[r * 4 + 3] + mvp[r * 4 + axis];
+            double acc = pl[0] * pl[0];
+            for (int r = 1; r < 4; ++r) acc = std::fma(pl[r], pl[r], acc);
+            const double n = std::sqrt(acc);
+            for (int r = 0; r < 4; ++r) planes[(2 * axis + sgn) * 4 + r] = pl[r] / n;
+        }
+}
+
 // The debug-frustum overlay's statement lists on the host (host_overlay.h): build into a per-thread buffer, report
 // the sizes, then copy out into arrays of those sizes.
 int mr_host_overlay_build(const double *corners, const double *planes, const double *mvp, const double *viewport,
