@@ -630,3 +630,27 @@ def test_cluster_culling_changes_nothing_but_the_work(api, name, monkeypatch):
         assert results["count"][5] > 0.25 * n_clusters, (results["count"][5], n_clusters)      # back faces of the torus
         assert results["count"][6] > results["count"][5]                                     # and what is not on the band's rows
     scene.close()
+
+
+def test_the_frames_bench_times_are_the_oracles_frames(api, oracle_mod):
+    """bench.py's timed region renders eight views of c4 (a 0.05-degree camera swing); only one of them is a reference
+    capture.  Every one of the eight against the C oracle at full size: z bit patterns, winners, stencil, the uint8
+    frame within 1 -- and the frame-only mode bench.py times against the counted one."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    scene = scenes.build(api, "c4_torus200k_1080p")
+    backend = scene._backend()
+    for k, (cam, dbg) in enumerate(bench.swing_cameras(api, scene, bench.N_VIEWS)):
+        scene.camera, scene.debug_camera = cam, dbg
+        out = backend.render(scene, shadows=True)
+        z, winner, stencil = backend.read_z(), backend.read_winner(), backend.read_stencil()
+        want = oracle_mod.render(scene, shadows=True, want_status=False, want_silhouette=False)
+        assert np.array_equal(z.view(np.uint64), want.z.view(np.uint64)), f"view {k}: z"
+        assert np.array_equal(winner, want.winner), f"view {k}: winners"
+        assert np.array_equal(stencil, want.stencil), f"view {k}: stencil"
+        assert np.abs(out.astype(np.int16) - want.out.astype(np.int16)).max() <= 1, f"view {k}: frame"
+        assert np.array_equal(backend.render(scene, shadows=True, counters=False), out), f"view {k}: frame-only mode"
+    scene.close()
