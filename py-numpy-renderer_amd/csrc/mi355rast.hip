@@ -121,6 +121,7 @@ struct FrameSlot {
     mr_frame_desc last_frame = {};
     int last_n_tiles = 0;
     bool last_ordered = false;               // the last frame's tile kernel followed the order buffer (else row-major)
+    bool overlay_deferred = false;           // the last enqueue_frame left the overlay to finish_overlay
     bool have_frame = false, stats_reduced = false;
     bool last_copied = false;                // the last frame was followed by a timed device-to-host copy (mr_render, mr_render_async)
 
@@ -180,6 +181,14 @@ struct mr_scene {
     // debug-frustum overlay: the lines' points as built on the host (five targets and a depth per point, segment by
     // segment); every frame slot keeps its own device copy (FrameSlot::ov), brought up to date when a frame of that
     // slot draws the overlay
+    // mr_scene_set_overlay_cameras only leaves its arguments here; the lists are built when first needed (realize_overlay)
+    // -- for mr_render / mr_render_async AFTER the frame's three kernels have been launched, so that the host walks the
+    // lines while the device renders (the lists' only early use, the tile kernel's tap mask, is given up for that frame)
+    struct OvPending {
+        bool set = false;
+        double corners[32], planes[24], mvp[16], viewport[16], near_ = 0, far_ = 0;
+        int32_t inside = 0, height = 0, width = 0;
+    } ov_pending;
     int32_t ov_height = 0, ov_width = 0;     // the frame the lists were built for
     int32_t ov_points = 0, ov_segments = 0;
     uint64_t ov_serial = 0;                  // bumped whenever the lists change
@@ -568,6 +577,32 @@ size_t out_bytes(const mr_frame_desc *fr)
     return (size_t)(fr->row_end - fr->row_begin) * fr->width * 3;
 }
 
+// Builds the overlay's lists from the cameras mr_scene_set_overlay_cameras left (host_overlay.h: clipping, projection,
+// DDA, dashes, index wrapping -- obj/frustums.py:61-103, obj/line.py:6-16), if that has not happened yet.
+void realize_overlay(mr_scene *sc)
+{
+    mr_scene::OvPending &p = sc->ov_pending;
+    if (!p.set) return;
+    p.set = false;
+    static const int32_t faces[24] = { 2, 4, 5, 3,  0, 1, 7, 6,  0, 2, 3, 1,  5, 4, 6, 7,  3, 5, 7, 1,  4, 2, 0, 6 };
+    static thread_local mr_host::OverlayLists lists;            // (its vectors keep their capacity from call to call)
+    lists.seg_first.clear(); lists.seg_count.clear(); lists.z.clear();
+    mr_host::build_overlay_lists(p.corners, faces, p.planes, p.mvp, p.viewport, p.near_, p.far_, p.inside != 0, p.height, p.width, 13,
+                                 lists, false, true);
+    sc->ov_points = sc->ov_segments = 0;
+    sc->ov_serial += 1;
+    if (lists.z.empty()) return;
+    const size_t np = lists.z.size();
+    sc->ov_target.resize((size_t)mr::OVERLAY_TARGETS * np);
+    for (int k = 0; k < mr::OVERLAY_TARGETS; ++k) std::copy(lists.target[k].begin(), lists.target[k].end(), sc->ov_target.begin() + (size_t)k * np);
+    sc->ov_z.assign(lists.z.begin(), lists.z.end());
+    sc->ov_seg.resize(2 * lists.seg_first.size());
+    for (size_t i = 0; i < lists.seg_first.size(); ++i) { sc->ov_seg[2 * i] = lists.seg_first[i]; sc->ov_seg[2 * i + 1] = lists.seg_count[i]; }
+    sc->ov_tile_mask.swap(lists.tile_mask);
+    sc->ov_height = p.height; sc->ov_width = p.width;
+    sc->ov_points = (int32_t)np; sc->ov_segments = (int32_t)lists.seg_first.size();
+}
+
 void fill_overlay_args(const mr_scene *sc, const FrameSlot *fs, mr::OverlayArgs &oa)
 {
     const char *base = static_cast<const char *>(fs->ov.lists.p);
@@ -636,7 +671,37 @@ int sync_slot_overlay(mr_scene *sc, FrameSlot *fs, bool with_slots = false)
 }
 
 // Enqueues one frame on the slot's stream.  d_out receives the uint8 rows.
-int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t *d_out)
+// The overlay kernel on the slot's own z-buffer and float frame (so the debug taps show them after the overlay, like
+// upstream's), finalising the touched pixels into d_out.
+void launch_overlay(mr_scene *sc, FrameSlot *fs, uint8_t *d_out, int width, int height, int system, hipStream_t stream)
+{
+    mr::OverlayArgs oa;
+    fill_overlay_args(sc, fs, oa);
+    oa.st_z = fs->d_z.as<double>(); oa.st_f = fs->d_frame.as<float>(); oa.out = d_out;
+    oa.out_width = width; oa.out_height = height;
+    oa.gamma_lut = sc->d_gamma.as<float>();
+    hipLaunchKernelGGL(mr::k_overlay, dim3(1), dim3(mr::OVERLAY_BLOCK), 0, stream, oa, (double)system);
+}
+
+// Second half of a frame whose overlay enqueue_frame left for later (may_defer_overlay): the device is busy with the
+// frame's three kernels, the host builds the lines' lists meanwhile, then the upload and the overlay kernel follow on the
+// frame's stream.
+int finish_overlay(mr_scene *sc, FrameSlot *fs, uint8_t *d_out)
+{
+    if (!fs->overlay_deferred) return MR_OK;
+    fs->overlay_deferred = false;
+    realize_overlay(sc);
+    if (sc->ov_points == 0) return MR_OK;
+    const mr_frame_desc &fr = fs->last_frame;
+    if (sc->ov_width != fr.width || sc->ov_height != fr.height) return fail(MR_E_INVALID, "overlay lists were built for a frame of another size");
+    int rc = sync_slot_overlay(sc, fs, false);
+    if (rc) return rc;
+    launch_overlay(sc, fs, d_out, fr.width, fr.height, fr.system, fs->stream);
+    HIP_TRY(hipGetLastError());
+    return MR_OK;
+}
+
+int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t *d_out, bool may_defer_overlay = false)
 {
     using namespace mr;
     int rc = commit(sc);
@@ -644,18 +709,24 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
     hipStream_t stream = fs->stream;
     FrameConst fc = make_const(sc, fr);
     if (fc.flags & MR_FRAME_FACE_STATUS) fc.flags |= MR_FRAME_KEEP_BUFFERS;
-    const bool overlay = (fc.flags & MR_FRAME_OVERLAY) && sc->ov_points > 0;
+    // (the lists of cameras left by mr_scene_set_overlay_cameras: built now -- or, for a whole frame of a caller that
+    // finishes it with finish_overlay, after the frame's kernels have been launched)
+    const bool partial = fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1;
+    const bool deferred = may_defer_overlay && (fc.flags & MR_FRAME_OVERLAY) && sc->ov_pending.set && !partial &&
+                          sc->ov_pending.width == fc.width && sc->ov_pending.height == fc.height;
+    if ((fc.flags & MR_FRAME_OVERLAY) && !deferred) realize_overlay(sc);
+    fs->overlay_deferred = deferred;
+    const bool overlay = (fc.flags & MR_FRAME_OVERLAY) && sc->ov_points > 0 && !deferred;
     // did the caller ask for the z / stencil / winner / float-frame taps?  (The overlay needs z and colour too, but
     // only at the pixels its lines touch: then only the tiles that hold such a pixel write them, ov_off[7].)
     const bool taps_asked = (fc.flags & (MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT)) != 0;
     // a device that owns only part of the frame (a rank of a multi-GPU split) cannot replay the overlay: its lines test
     // z at pixels other devices own.  It appends the state of the touched pixels it owns to its rows instead
     // (k_overlay_export), and the overlay is replayed on the assembled frame (mr_overlay_apply).
-    const bool partial = fr->row_begin != 0 || fr->row_end != fr->height || fr->stripe_count > 1;
     if (fc.flags & MR_FRAME_OVERLAY) {
         if (partial && fr->stripe_count <= 1 && (fr->height % (fr->row_end - fr->row_begin) || fr->row_begin % (fr->row_end - fr->row_begin)))
             return fail(MR_E_INVALID, "overlay on a row band: the bands of the split must be equal");
-        if (sc->ov_points > 0 && (sc->ov_width != fc.width || sc->ov_height != fc.height))
+        if (!deferred && sc->ov_points > 0 && (sc->ov_width != fc.width || sc->ov_height != fc.height))
             return fail(MR_E_INVALID, "overlay lists were built for a frame of another size");
         if (overlay && (rc = sync_slot_overlay(sc, fs, partial))) return rc;
         fc.flags |= MR_FRAME_KEEP_BUFFERS | MR_FRAME_KEEP_FLOAT;
@@ -870,13 +941,7 @@ int enqueue_frame(mr_scene *sc, FrameSlot *fs, const mr_frame_desc *fr, uint8_t 
                            reinterpret_cast<const int32_t *>(static_cast<const char *>(fs->ov.lists.p) + fs->ov.off[5]), n_slots,
                            fs->d_z.as<double>(), fs->d_frame.as<float>(), fc.width, fc.height, world, fr->stripe_count > 1 ? 1 : 0, rank, state);
     } else if (overlay) {                   // after the lit pass' per-face verdicts, as in obj/core.py:624-638
-        OverlayArgs oa;
-        fill_overlay_args(sc, fs, oa);
-        // on the frame's own z-buffer and float frame (so the debug taps show them after the overlay, like upstream's)
-        oa.st_z = fs->d_z.as<double>(); oa.st_f = fs->d_frame.as<float>(); oa.out = d_out;
-        oa.out_width = fc.width; oa.out_height = fc.height;
-        oa.gamma_lut = sc->d_gamma.as<float>();
-        hipLaunchKernelGGL(k_overlay, dim3(1), dim3(OVERLAY_BLOCK), 0, stream, oa, (double)fc.system);
+        launch_overlay(sc, fs, d_out, fc.width, fc.height, fc.system, stream);
     }
     HIP_TRY(hipGetLastError());
     fs->last_frame = *fr;
@@ -1108,6 +1173,7 @@ int mr_scene_set_overlay(mr_scene *sc, const mr_overlay_desc *ov)
     if (!sc) return fail(MR_E_INVALID, "scene is NULL");
     int rc = ensure_init();
     if (rc) return rc;
+    sc->ov_pending.set = false;                          // explicit lists supersede cameras left earlier
     sc->ov_points = sc->ov_segments = 0;                 // (frames already enqueued keep the lists of their slot's copy)
     sc->ov_serial += 1;
     if (!ov || ov->n_points <= 0 || ov->n_segments <= 0) return MR_OK;
@@ -1155,23 +1221,11 @@ int mr_scene_set_overlay_cameras(mr_scene *sc, const double *corners, const doub
         return fail(MR_E_INVALID, "mr_scene_set_overlay_cameras: bad argument");
     int rc = ensure_init();
     if (rc) return rc;
-    static const int32_t faces[24] = { 2, 4, 5, 3,  0, 1, 7, 6,  0, 2, 3, 1,  5, 4, 6, 7,  3, 5, 7, 1,  4, 2, 0, 6 };
-    static thread_local mr_host::OverlayLists lists;            // (its vectors keep their capacity from call to call)
-    lists.seg_first.clear(); lists.seg_count.clear(); lists.z.clear();
-    mr_host::build_overlay_lists(corners, faces, planes, mvp, viewport, near_, far_, camera_inside != 0, height, width, 13,
-                                 lists, false, true);
-    sc->ov_points = sc->ov_segments = 0;
-    sc->ov_serial += 1;
-    if (lists.z.empty()) return MR_OK;
-    const size_t np = lists.z.size();
-    sc->ov_target.resize((size_t)mr::OVERLAY_TARGETS * np);
-    for (int k = 0; k < mr::OVERLAY_TARGETS; ++k) std::copy(lists.target[k].begin(), lists.target[k].end(), sc->ov_target.begin() + (size_t)k * np);
-    sc->ov_z.assign(lists.z.begin(), lists.z.end());
-    sc->ov_seg.resize(2 * lists.seg_first.size());
-    for (size_t i = 0; i < lists.seg_first.size(); ++i) { sc->ov_seg[2 * i] = lists.seg_first[i]; sc->ov_seg[2 * i + 1] = lists.seg_count[i]; }
-    sc->ov_tile_mask.swap(lists.tile_mask);
-    sc->ov_height = height; sc->ov_width = width;
-    sc->ov_points = (int32_t)np; sc->ov_segments = (int32_t)lists.seg_first.size();
+    mr_scene::OvPending &p = sc->ov_pending;
+    std::memcpy(p.corners, corners, sizeof p.corners); std::memcpy(p.planes, planes, sizeof p.planes);
+    std::memcpy(p.mvp, mvp, sizeof p.mvp); std::memcpy(p.viewport, viewport, sizeof p.viewport);
+    p.near_ = near_; p.far_ = far_; p.inside = camera_inside; p.height = height; p.width = width;
+    p.set = true;
     return MR_OK;
 }
 
@@ -1262,7 +1316,8 @@ int mr_render(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, mr_stats 
     const size_t band_bytes = out_bytes(fr);
     for (int attempt = 0; attempt < 6; ++attempt) {
         HIP_TRY(fs->d_out.ensure(band_bytes));
-        if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
+        if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>(), true))) return rc;
+        if ((rc = finish_overlay(sc, fs, fs->d_out.as<uint8_t>()))) return rc;      // (the host's share of the overlay, beside the device's kernels)
         if ((rc = fetch_counters(sc, fs, stats != nullptr))) return rc;
         HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, g_stream));
         if (!(fr->flags & MR_FRAME_NO_TIMING)) { HIP_TRY(hipEventRecord(fs->ev[5], g_stream)); fs->last_copied = true; }
@@ -1293,7 +1348,8 @@ int mr_render_async(mr_scene *sc, const mr_frame_desc *fr, uint8_t *out_rgb, int
     if (!fs) return fail(MR_E_DEVICE, "out of frame slots");
     const size_t band_bytes = out_bytes(fr);
     HIP_TRY(fs->d_out.ensure(band_bytes));
-    if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>()))) return rc;
+    if ((rc = enqueue_frame(sc, fs, fr, fs->d_out.as<uint8_t>(), true))) return rc;
+    if ((rc = finish_overlay(sc, fs, fs->d_out.as<uint8_t>()))) return rc;
     if ((rc = fetch_counters(sc, fs, (fr->flags & MR_FRAME_COUNTERS) != 0))) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgb, fs->d_out.p, band_bytes, hipMemcpyDeviceToHost, ln.stream));
     if (!(fr->flags & MR_FRAME_NO_TIMING)) { HIP_TRY(hipEventRecord(fs->ev[5], ln.stream)); fs->last_copied = true; }
@@ -1320,6 +1376,7 @@ int mr_render_wait(mr_scene *sc, int32_t lane, mr_stats *stats)
 int64_t mr_overlay_state_bytes(mr_scene *sc)
 {
     if (!sc) return fail(MR_E_INVALID, "scene is NULL");
+    realize_overlay(sc);
     if (sc->ov_points == 0) return 0;
     ensure_overlay_slots(sc);
     return (int64_t)sc->ov_touched.size() * mr::OVERLAY_STATE_BYTES;
@@ -1331,6 +1388,7 @@ int mr_overlay_apply(mr_scene *sc, const void *d_parts, int64_t part_stride, int
     using namespace mr;
     if (!sc || !d_parts || !d_frame) return fail(MR_E_INVALID, "NULL argument");
     if (world < 1 || part_stride <= 0 || state_offset < 0 || (system != 1 && system != -1)) return fail(MR_E_INVALID, "mr_overlay_apply: bad argument");
+    realize_overlay(sc);
     if (sc->ov_points == 0) return MR_OK;
     if (!striped && sc->ov_height % world) return fail(MR_E_INVALID, "mr_overlay_apply: the bands of the split must be equal");
     int rc = ensure_init();
