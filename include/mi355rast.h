@@ -212,7 +212,8 @@ int mr_scene_set_overlay(mr_scene *scene, const mr_overlay_desc *overlay);
 
 /* The same overlay straight from the two cameras, everything on the host side of the library in one call
  * (replaces obj/frustums.py:61-103 + obj/line.py:6-16: clipping, projection, DDA, dashes, index wrapping; the
- * upload is one asynchronous copy in front of the next frame that draws the overlay): the frustum's eight corners
+ * upload is one asynchronous copy in front of the overlay kernel of the next frame that draws it; the lists are built
+ * when first needed -- by mr_render / mr_render_async after the frame's kernels have been launched): the frustum's eight corners
  * (8 x 4, already divided by w: CUBE @ inv(debug MVP), obj/frustums.py:52-53), the viewing camera's six planes
  * (6 x 4), its MVP and viewport (4 x 4, row vectors), near / far, whether the viewing camera sits inside the
  * frustum (obj/frustums.py:57-60), and the frame's size. */
