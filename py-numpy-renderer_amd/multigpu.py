@@ -33,36 +33,55 @@ def row_band(height, rank, world):
     return rank * rows, (rank + 1) * rows
 
 
-def tile_row_costs(records, tiles_x):
+RESIDENT_WORKGROUPS = 256 * 6      # tile workgroups an MI355X holds at once (256 CUs, six wavefronts per SIMD, four per workgroup)
+
+
+def tile_row_costs(records, tiles_x, peaks=False):
     """Cost of every tile row of a whole frame (bottom row first), from the tile kernel's per-tile records of that
     frame (``DeviceRenderer.read_tile_records``: words 5-7 are the lengths of a tile's three lists) with the kernel's
     own cost model (``tile_cost`` in csrc/kernels_tile.h: 20 + 2 small pairs + 30 big pairs + 3 shadow quads, in
-    units of ~0.1 us)."""
+    units of ~0.1 us).  With *peaks* also the cost of every row's most expensive tile."""
     import numpy as np
     rec = np.asarray(records, dtype=np.int64)
-    cost = 20 + 2 * rec[:, 5] + 30 * rec[:, 6] + 3 * rec[:, 7]
-    return cost.reshape(-1, int(tiles_x)).sum(axis=1)
+    cost = (20 + 2 * rec[:, 5] + 30 * rec[:, 6] + 3 * rec[:, 7]).reshape(-1, int(tiles_x))
+    return (cost.sum(axis=1), cost.max(axis=1)) if peaks else cost.sum(axis=1)
 
 
-def weighted_bands(row_cost, height, world):
+def weighted_bands(row_cost, height, world, row_peak=None, resident=RESIDENT_WORKGROUPS):
     """Contiguous bands of output rows ``[(begin, end)] * world`` (rank 0 on top, every band at least one tile row, cut
     on tile rows) that minimise the cost of the most expensive band; *row_cost* lists the tile rows bottom first
-    (screen y up, like the reference's buffers and the device's tile grid)."""
+    (screen y up, like the reference's buffers and the device's tile grid).
+
+    The cost of a band is the sum of its tiles' costs -- or, with *row_peak* (the most expensive tile of every row),
+    a model of what the tile kernel's launch on that band lasts: the device works on *resident* tiles at once, so a
+    band takes its summed cost / *resident*, plus a tail behind its most expensive tile (a fifth of that tile's cost:
+    what c3's and c4's whole frames show, 48.5 + 0.2 x 117 = 73 us and 45.5 + 0.2 x 81 = 60 us).  A thin band under
+    the heaviest tiles of the frame is mostly tail, and taking rows from it does not make it faster."""
     cost = [int(c) for c in row_cost][::-1]                  # top tile row first: bands are handed out in output order
+    peak = [int(c) for c in row_peak][::-1] if row_peak is not None else None
     n = len(cost)
     if n != -(-int(height) // TILE_ROWS):
         raise ValueError(f"{n} tile-row costs for {height} rows")
     if not 1 <= world <= n:
         raise ValueError(f"{world} ranks for {n} tile rows")
+    if peak is not None and len(peak) != n:
+        raise ValueError("row_peak and row_cost differ in length")
+
+    def band_cost(total, top):
+        return total if peak is None else total + top * int(resident) // 5     # (in units of cost / resident)
 
     def cuts_for(cap):
         """Greedy: every band takes tile rows while it stays under *cap* and leaves one for each rank behind it."""
         cuts, at = [], 0
         for r in range(world):
             last = n - (world - 1 - r)                       # rows [at, last) are this band's to choose from
-            acc, end = 0, at
-            while end < last and (end == at or acc + cost[end] <= cap):
+            acc, top, end = 0, 0, at
+            while end < last:
+                nxt_top = max(top, peak[end]) if peak is not None else 0
+                if end > at and band_cost(acc + cost[end], nxt_top) > cap:
+                    break
                 acc += cost[end]
+                top = nxt_top
                 end += 1
             if r == world - 1 and end < n:
                 return None
@@ -70,17 +89,43 @@ def weighted_bands(row_cost, height, world):
             at = end
         return cuts
 
-    lo, hi = max(cost), sum(cost)
+    lo = max(band_cost(c, p) for c, p in zip(cost, peak if peak is not None else [0] * n))
+    hi = band_cost(sum(cost), max(peak) if peak is not None else 0)
     while lo < hi:                                           # smallest cap the greedy split fits under
         mid = (lo + hi) // 2
         if cuts_for(mid) is None:
             lo = mid + 1
         else:
             hi = mid
+    # Among the splits whose most expensive band costs no more than that, the one with the least sum of squared band
+    # costs: the greedy split fills every band up to the cap, and where one band is dear whatever its size (a heavy tile's
+    # tail) that would starve the bands behind it for no gain.  (rows^2 x ranks steps, once per renderer.)
+    cap = lo
+    inf = float("inf")
+    best = [[inf] * (n + 1) for _ in range(world + 1)]
+    cut = [[0] * (n + 1) for _ in range(world + 1)]
+    best[0][0] = 0
+    for r in range(1, world + 1):
+        for i in range(r, n - (world - r) + 1):
+            acc, top = 0, 0
+            for j in range(i - 1, r - 2, -1):                 # band = rows [j, i)
+                acc += cost[j]
+                if peak is not None:
+                    top = max(top, peak[j])
+                c = band_cost(acc, top)
+                if c > cap:
+                    break
+                if best[r - 1][j] + c * c < best[r][i]:
+                    best[r][i], cut[r][i] = best[r - 1][j] + c * c, j
+    cuts, i = [], n
+    for r in range(world, 0, -1):
+        cuts.append((cut[r][i], i))
+        i = cut[r][i]
+    cuts.reverse()
     top_rows = int(height) - (n - 1) * TILE_ROWS            # the top tile row may be a partial one
     def first_row(t):                                        # output row where tile row t (from the top) begins
         return 0 if t == 0 else top_rows + (t - 1) * TILE_ROWS
-    return [(first_row(a), int(height) if b == n else first_row(b)) for a, b in cuts_for(lo)]
+    return [(first_row(a), int(height) if b == n else first_row(b)) for a, b in cuts]
 
 
 def unband_index(bands, device=None):
@@ -234,8 +279,8 @@ class BandRenderer:
             torch.cuda.current_stream().synchronize()
             if not self.backend.overflowed():
                 break
-        costs = tile_row_costs(self.backend.read_tile_records(), -(-width // 16))
-        return weighted_bands(costs, height, world)
+        costs, peaks = tile_row_costs(self.backend.read_tile_records(), -(-width // 16), peaks=True)
+        return weighted_bands(costs, height, world, row_peak=peaks)
 
     def prime(self):
         """One frame per lane through the full host path (scene sync, frame packing); repeated while

@@ -57,9 +57,23 @@ def test_weighted_bands_cut_on_tile_rows_and_balance_the_cost():
     assert weighted_bands([100] * 10 + [1] * 58, 1080, 4) == [(0, 952), (952, 1000), (1000, 1048), (1048, 1080)]
     with pytest.raises(ValueError):
         weighted_bands(np.ones(5), 1080, 2)
+    # with the rows' most expensive tiles: a band's cost is its sum plus a tail behind its heaviest tile (a fifth of that
+    # tile's cost times the tiles the device holds at once), so the band under one very heavy tile gets fewer rows
+    flat, spike = [100] * 68, [10] * 68
+    spike[30] = 400
+    even = weighted_bands(flat, 1080, 4, row_peak=[10] * 68, resident=100)
+    tilted = weighted_bands(flat, 1080, 4, row_peak=spike, resident=100)
+    rows = lambda bands: [e - b for b, e in bands]
+    assert max(rows(even)) - min(rows(even)) <= 16 + 8                 # (the top tile row of 1080 is half a row)
+    heavy = [i for i, (b, e) in enumerate(tilted) if b <= 1080 - 16 * 31 < e][0]      # the band that holds tile row 30 (from the bottom)
+    assert rows(tilted)[heavy] < min(r for i, r in enumerate(rows(tilted)) if i != heavy)
+    with pytest.raises(ValueError):
+        weighted_bands(flat, 1080, 4, row_peak=[1] * 5)
     rec = np.zeros((6, 12), np.uint32)
     rec[:, 5], rec[:, 6], rec[:, 7] = [1, 0, 0, 0, 2, 0], [0, 1, 0, 0, 0, 0], [0, 0, 5, 0, 0, 0]
     assert tile_row_costs(rec, 3).tolist() == [20 + 2 + 20 + 30 + 20 + 15, 20 + 20 + 4 + 20]
+    sums, peaks = tile_row_costs(rec, 3, peaks=True)
+    assert sums.tolist() == [107, 64] and peaks.tolist() == [50, 24]
 
 
 def stripe_pack(frame, rank, world):

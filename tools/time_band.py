@@ -38,7 +38,7 @@ def per_frame(world, rank, partition, frames=300):
 
 print(name, "whole frame us", round(per_frame(1, 0, "bands"), 1), flush=True)
 for n in (int(a) for a in sys.argv[2:]):
-    for partition in ("bands", "stripes", "weighted"):
+    for partition in os.environ.get("PARTITIONS", "bands stripes weighted").split():
         if partition == "bands" and h % n:
             continue
         t = [per_frame(n, r, partition) for r in range(n)]
