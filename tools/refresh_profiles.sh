@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: everything under profiles/<round>_* that depends on the kernels, in one go (about 4 GPU-minutes).
+# GPU box: everything under profiles/<round>_* that depends on the kernels, in one go (about 6 GPU-minutes).
 # Results land in gpurun_out/refresh/ under their profiles/ names; copy them over afterwards:
 #   gpurun -- 'bash tools/refresh_profiles.sh r03' && cp gpurun_out/refresh/r03_* profiles/ && python tools/make_traffic_json.py r03 c2 c3 c4 c5
 rnd=${1:-r03}
@@ -31,6 +31,11 @@ grep "c4_torus" gpurun_out/prof/scene_render/run.log > $R/${rnd}_c4_scene_render
 # bench lines without the profiler (c4 with the CPU baseline: the line the driver records)
 for c in c2 c3 c5; do timeout -k 10 600 python bench.py --config $c --no-cpu-baseline > $R/${rnd}_bench_$c.json 2> $R/bench_$c.err || exit 1; done
 timeout -k 10 900 python bench.py > $R/${rnd}_bench_c4.json 2> $R/bench_c4.err || exit 1
+# what one rank of a split frame costs this device (no collective), per partition; and the atomics micro-benchmark
+python3 tools/time_band.py c4_torus200k_1080p 2 4 8 2>&1 | grep -v amdgpu.ids > $R/${rnd}_partition_per_rank_times.txt
+python3 tools/time_band.py c5_torus1m_4k_skybox 2 4 8 2>&1 | grep -v amdgpu.ids >> $R/${rnd}_partition_per_rank_times.txt
+PARTITIONS="stripes weighted" python3 tools/time_band.py c3_diablo_floor_1080p 2 4 8 2>&1 | grep -v amdgpu.ids >> $R/${rnd}_partition_per_rank_times.txt
+hipcc -O3 --offload-arch=gfx950 -o tools/micro/atomic_same_addr tools/micro/atomic_same_addr.hip && tools/micro/atomic_same_addr > $R/${rnd}_atomic_same_address.txt 2>&1
 # the raw traces stay on the box: gpurun copies back at most 64 MiB
 rm -rf gpurun_out/prof gpurun_out/pmc
 ls -la $R
