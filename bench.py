@@ -291,7 +291,7 @@ def main():
         elapsed = float(t.item())
     n_frames = args.steps * fps
     assert br.verify(), "a work list overflowed in the timed frames"
-    ktimes, n_avg = br.kernel_times(64)
+    ktimes, n_avg = br.kernel_times(2048)            # every marked frame still in the streams' event rings (~40 each)
     last_frame = br.frame
 
     # the frame every rank now holds must be the frame a single device renders for that view

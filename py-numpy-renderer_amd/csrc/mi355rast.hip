@@ -83,7 +83,7 @@ struct EdgeKey {
 
 // Event marks of one frame:
 //   0 start | 1 after k_vertex_mfma (optional) | 2 after k_setup | 3 after k_bin_work | 4 after k_tile | 5 device->host copy
-constexpr int EVENT_RING = 64, N_MARKS = 6;
+constexpr int EVENT_RING = 512, N_MARKS = 6;     // (bench.py marks one frame in 13: ~40 marked frames per stream to average over)
 
 // Everything one in-flight frame writes.
 struct FrameSlot {
