@@ -46,12 +46,12 @@ edits = [
     ("    else edge_block(b - face_blocks);", "    else if (MR_ABLATE != 11 && MR_ABLATE != 17) edge_block(b - face_blocks);"),
     # 60: time stamps along the chain of a wavefront that has silhouette edges (lane 0; sums, maxima and the count in the
     #     counters' padding words, printed by the host when MR_SETUP_TIMES is set): stage k = DBG_T(k)
-    ("    unsigned long long todo = __ballot(sil);\n", "    g_dbg_t0 = __builtin_amdgcn_s_memrealtime();\n    unsigned long long todo = __ballot(sil);\n    if (todo) { DBG_T(0); }\n"),
+    ("    unsigned long long todo0 = __ballot(sil[0]), todo1 = __ballot(sil[1]);\n", "    g_dbg_t0 = __builtin_amdgcn_s_memrealtime();\n    unsigned long long todo0 = __ballot(sil[0]), todo1 = __ballot(sil[1]);\n    if (todo0 | todo1) { DBG_T(0); }\n"),
     ("    // ---- clipping, one plane at a time\n", "    DBG_T(1);\n    // ---- clipping, one plane at a time\n"),
     ("    const bool alive = n >= 3;                           // obj/triangular.py:322-323\n", "    DBG_T(2);\n    const bool alive = n >= 3;                           // obj/triangular.py:322-323\n"),
     ("    double xs[2] = { lo_x, hi_x }, ys[2] = { lo_y, hi_y };\n", "    DBG_T(3);\n    double xs[2] = { lo_x, hi_x }, ys[2] = { lo_y, hi_y };\n"),
     ("    if (!boxed) return;\n    if (slot >= sa.quad_cap)", "    DBG_T(4);\n    if (!boxed) return;\n    if (slot >= sa.quad_cap)"),
-    ("    const uint32_t my_slot = (uint32_t)__shfl((int)base_raw, 0) + my_rank;\n", "    __builtin_amdgcn_s_waitcnt(0); DBG_T(5);\n    const uint32_t my_slot = (uint32_t)__shfl((int)base_raw, 0) + my_rank;\n"),
+    ("    const uint32_t base = (uint32_t)__shfl((int)base_raw, 0);\n", "    __builtin_amdgcn_s_waitcnt(0); DBG_T(5);\n    const uint32_t base = (uint32_t)__shfl((int)base_raw, 0);\n"),
 ]
 for a, b in edits:
     assert s.count(a) == 1, a
